@@ -1,0 +1,675 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE implementation (imported from /root/reference, CPU, fp32) on
+seeded inputs and writes input/output fixtures to tests/golden/*.npz.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (the reference never travels to the GPU box);
+the committed .npz files are data: inputs, recorded noise tensors and the reference's outputs.
+
+    PYTHONPATH=/root/reference python3 oracle/gen_golden.py
+
+The absent third-party wheels are stubbed in-process:
+  * flash_attn.flash_attn_interface.flash_attn_varlen_qkvpacked_func -> exact fp32 softmax attention
+    (non-causal, scale d^-1/2, equal-length sequences), the definition this build adopts for that boundary;
+  * flash_attn.ops.fused_dense / omegaconf -> empty name holders (never called on this path).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = os.environ.get("SEDD_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+
+# ----------------------------------------------------------------------------------------------- stubs
+def _install_stubs():
+    fa = types.ModuleType("flash_attn")
+    fai = types.ModuleType("flash_attn.flash_attn_interface")
+
+    def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None,
+                                         causal=False, **kw):
+        assert dropout_p == 0.0 and not causal
+        total, three, H, d = qkv.shape
+        B = cu_seqlens.numel() - 1
+        L = total // B
+        q, k, v = qkv.view(B, L, 3, H, d).float().unbind(2)
+        s = torch.einsum("blhd,bmhd->bhlm", q, k) * (d ** -0.5)
+        p = torch.softmax(s, dim=-1)
+        o = torch.einsum("bhlm,bmhd->blhd", p, v)
+        return o.reshape(total, H, d).to(qkv.dtype)
+
+    fai.flash_attn_varlen_qkvpacked_func = flash_attn_varlen_qkvpacked_func
+    ops = types.ModuleType("flash_attn.ops")
+    fd = types.ModuleType("flash_attn.ops.fused_dense")
+    fd.FusedMLP = object
+    fd.FusedDense = object
+    fa.flash_attn_interface = fai
+    fa.ops = ops
+    ops.fused_dense = fd
+    sys.modules.update({"flash_attn": fa, "flash_attn.flash_attn_interface": fai, "flash_attn.ops": ops,
+                        "flash_attn.ops.fused_dense": fd})
+    oc = types.ModuleType("omegaconf")
+
+    class OmegaConf:  # noqa
+        @staticmethod
+        def create(d):
+            return d
+
+    oc.OmegaConf = OmegaConf
+    sys.modules["omegaconf"] = oc
+
+
+_install_stubs()
+
+import builtins  # noqa: E402
+
+_real_print = builtins.print
+
+from protlig_dd.processing import graph_lib, noise_lib, losses  # noqa: E402
+from protlig_dd.sampling import sampling  # noqa: E402
+from protlig_dd.utils import catsample  # noqa: E402
+from protlig_dd.model import transformer as ref_tf  # noqa: E402
+from protlig_dd.model import transformers_protlig_cross as ref_cross  # noqa: E402
+from protlig_dd.model import rotary as ref_rotary  # noqa: E402
+from protlig_dd.model.ema import ExponentialMovingAverage  # noqa: E402
+
+from oracle.weights import load_seeded  # noqa: E402
+
+NS = types.SimpleNamespace
+
+
+def quiet(fn, *a, **k):
+    """The reference prints shapes inside forward(); silence it while generating."""
+    builtins.print = lambda *aa, **kk: None
+    try:
+        return fn(*a, **k)
+    finally:
+        builtins.print = _real_print
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    _real_print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def sedd_config(hidden, heads, cond, blocks, tokens=25, graph="absorb", dropout=0.0, scale_by_sigma=True):
+    return NS(tokens=tokens, graph=NS(type=graph),
+              model=NS(hidden_size=hidden, n_heads=heads, cond_dim=cond, n_blocks=blocks, dropout=dropout,
+                       scale_by_sigma=scale_by_sigma, length=128))
+
+
+class RecordRand:
+    """Context manager: records every torch.rand / rand_like / randint_like the reference draws."""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._rand, self._rand_like, self._randint_like = torch.rand, torch.rand_like, torch.randint_like
+        log = self.log
+
+        def rand(*a, **k):
+            r = self._rand(*a, **k)
+            log.append(("rand", r.clone()))
+            return r
+
+        def rand_like(*a, **k):
+            r = self._rand_like(*a, **k)
+            log.append(("rand_like", r.clone()))
+            return r
+
+        def randint_like(*a, **k):
+            r = self._randint_like(*a, **k)
+            log.append(("randint_like", r.clone()))
+            return r
+
+        torch.rand, torch.rand_like, torch.randint_like = rand, rand_like, randint_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.rand_like, torch.randint_like = self._rand, self._rand_like, self._randint_like
+
+
+# ----------------------------------------------------------------------------------------------- G1
+def g1_noise():
+    t = torch.cat([torch.linspace(1e-3, 1.0, 61), torch.tensor([1e-5, 0.5, 0.999])])
+    out = {"t": t}
+    ll = noise_lib.LogLinearNoise(eps=1e-3)
+    out["loglinear_sigma"], out["loglinear_dsigma"] = ll(t)
+    ll2 = noise_lib.LogLinearNoise(eps=0.1)
+    out["loglinear01_sigma"], out["loglinear01_dsigma"] = ll2(t)
+    ge = noise_lib.GeometricNoise(1e-4, 20.0)
+    out["geometric_sigma"], out["geometric_dsigma"] = ge(t)
+    co = noise_lib.CosineNoise(1e-3, 1.0)
+    out["cosine_sigma"], out["cosine_dsigma"] = co(t)
+    save("g1_noise", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G2
+def g2_sample_transition():
+    torch.manual_seed(102)
+    out = {}
+    B, L = 6, 40
+    sigma = torch.tensor([1e-3, 0.05, 0.4, 0.7, 2.0, 6.9])[:, None]
+    out["sigma"] = sigma
+    for V, tag in ((26, "absorb26"), (2365, "absorb2365")):
+        g = graph_lib.Absorbing(V - 1)
+        x0 = torch.randint(0, V - 1, (B, L))
+        with RecordRand() as rr:
+            xt = g.sample_transition(x0, sigma)
+        out[tag + "_x0"], out[tag + "_u"], out[tag + "_xt"] = x0, rr.log[0][1], xt
+    g = graph_lib.Uniform(25)
+    x0 = torch.randint(0, 25, (B, L))
+    with RecordRand() as rr:
+        xt = g.sample_transition(x0, sigma)
+    out["uniform25_x0"], out["uniform25_u"], out["uniform25_r"], out["uniform25_xt"] = \
+        x0, rr.log[0][1], rr.log[1][1], xt
+    # curriculum variant (graph_lib.py:236-256) at a few training steps
+    g = graph_lib.Absorbing(25)
+    x0 = torch.randint(0, 25, (B, L))
+    out["curr_x0"] = x0
+    steps = [0, 99, 100, 300, 500, 999, 1000, 1200, 1500, 1999, 2000, 5000]
+    out["curr_steps"] = np.array(steps)
+    us, xts = [], []
+    for s in steps:
+        with RecordRand() as rr:
+            xt = g.sample_transition_curriculum(x0, sigma, s)
+        us.append(rr.log[0][1])
+        xts.append(xt)
+    out["curr_u"], out["curr_xt"] = torch.stack(us), torch.stack(xts)
+    save("g2_sample_transition", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G3
+def g3_score_entropy():
+    torch.manual_seed(103)
+    out = {}
+    for V, B, L in ((26, 4, 24), (37, 4, 24), (2365, 2, 8)):
+        g = graph_lib.Absorbing(V - 1)
+        sigma = torch.tensor([0.02, 0.3, 0.8, 5.0])[:B, None]
+        x0 = torch.randint(0, V - 1, (B, L))
+        x = torch.where(torch.rand(B, L) < 0.6, torch.full_like(x0, V - 1), x0)
+        x[0, :] = V - 1          # fully masked row
+        if B > 2:
+            x[1, :] = x0[1, :]   # fully unmasked row
+        score = (torch.randn(B, L, V) * 1.5).requires_grad_(True)
+        w = torch.randn(B, L)
+        se = g.score_entropy(score, sigma, x, x0)
+        (se * w).sum().backward()
+        t = f"absorb{V}_"
+        out.update({t + "sigma": sigma, t + "x": x, t + "x0": x0, t + "score": score, t + "w": w,
+                    t + "out": se, t + "grad": score.grad})
+    V, B, L = 25, 4, 24
+    g = graph_lib.Uniform(V)
+    sigma = torch.tensor([0.02, 0.3, 0.8, 5.0])[:, None]
+    x0 = torch.randint(0, V, (B, L))
+    x = torch.where(torch.rand(B, L) < 0.5, torch.randint(0, V, (B, L)), x0)
+    score = (torch.randn(B, L, V) * 1.5).requires_grad_(True)
+    w = torch.randn(B, L)
+    se = g.score_entropy(score, sigma, x, x0)
+    (se * w).sum().backward()
+    t = "uniform25_"
+    out.update({t + "sigma": sigma, t + "x": x, t + "x0": x0, t + "score": score, t + "w": w,
+                t + "out": se, t + "grad": score.grad})
+    save("g3_score_entropy", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G4
+def g4_graph_ops():
+    torch.manual_seed(104)
+    out = {}
+    B, L = 3, 20
+    for tag, g, V in (("absorb26", graph_lib.Absorbing(25), 26), ("uniform25", graph_lib.Uniform(25), 25)):
+        i = torch.randint(0, V, (B, L))
+        if g.absorb:
+            i[:, ::3] = V - 1
+        score = torch.randn(B, L, V).exp()
+        sigma = torch.tensor([0.03, 0.6, 3.0])[:, None]
+        t = tag + "_"
+        out[t + "i"], out[t + "score"], out[t + "sigma"] = i, score, sigma
+        out[t + "rate"] = g.rate(i)
+        out[t + "transp_rate"] = g.transp_rate(i)
+        out[t + "reverse_rate"] = g.reverse_rate(i, score)
+        out[t + "staggered_score"] = g.staggered_score(score, sigma)
+        out[t + "transp_transition"] = g.transp_transition(i, sigma)
+        if not g.absorb:
+            out[t + "transition"] = g.transition(i, sigma)
+        with RecordRand() as rr:
+            lim = g.sample_limit(B, L)
+        out[t + "sample_limit"] = lim
+        rev = 0.01 * sigma[..., None] * g.reverse_rate(i, score)
+        with RecordRand() as rr:
+            nxt = g.sample_rate(i, rev)
+        out[t + "sample_rate_rate"], out[t + "sample_rate_u"], out[t + "sample_rate_out"] = rev, rr.log[0][1], nxt
+    save("g4_graph_ops", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G5
+def g5_sample_categorical():
+    torch.manual_seed(105)
+    out = {}
+    for V, n in ((26, 512), (37, 256), (2365, 64)):
+        p = torch.rand(n, V) ** 3
+        p[::7] = 0.0
+        p[::7, 3] = 1.0                      # one-hot rows
+        p[1::11] = p[1::11].round()          # rows with many exact ties (0/1 values)
+        with RecordRand() as rr:
+            s = catsample.sample_categorical(p)
+        out[f"v{V}_p"], out[f"v{V}_u"], out[f"v{V}_out"] = p, rr.log[0][1], s
+    save("g5_sample_categorical", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G6
+class _FakeScoreModel:
+    """Returns fixed log-scores; accepts the Euler/Denoiser keyword signature (sampling.py:65-76)."""
+
+    def __init__(self, logits):
+        self.logits = logits
+        self.sigmas = []
+
+    def eval(self):
+        return self
+
+    def __call__(self, **kw):
+        self.sigmas.append(kw["timesteps"].clone())
+        return self.logits
+
+
+def g6_predictor_steps():
+    torch.manual_seed(106)
+    out = {}
+    for V, B, L, tag in ((26, 4, 32, "v26"), (2365, 2, 8, "v2365")):
+        graph = graph_lib.Absorbing(V - 1)
+        noise = noise_lib.LogLinearNoise(eps=1e-3)
+        x = torch.randint(0, V - 1, (B, L))
+        x = torch.where(torch.rand(B, L) < 0.7, torch.full_like(x, V - 1), x)
+        logits = torch.randn(B, L, V)
+        logits.scatter_(-1, x[..., None], torch.zeros(B, L, 1))
+        t = torch.tensor([0.9, 0.5, 0.2, 0.05])[:B, None]
+        dt = 1.0 / 16
+        out[tag + "_x"], out[tag + "_logits"], out[tag + "_t"], out[tag + "_dt"] = x, logits, t, np.float64(dt)
+        # Euler
+        m = _FakeScoreModel(logits)
+        with RecordRand() as rr:
+            xe = quiet(sampling.EulerPredictor(graph, noise).update_fn, score_model=m, x=x, t=t, step_size=dt,
+                       task="protein_only")
+        out[tag + "_euler_u"], out[tag + "_euler_out"], out[tag + "_sigma_seen"] = rr.log[0][1], xe, m.sigmas[0]
+        # Analytic (upstream positional signature): score_fn returns exp(logits)
+        with RecordRand() as rr:
+            xa = sampling.AnalyticPredictor(graph, noise).update_fn(lambda xx, s: logits.exp(), x, t, dt)
+        out[tag + "_analytic_u"], out[tag + "_analytic_out"] = rr.log[0][1], xa
+        # Denoiser at t = eps
+        te = torch.full((B, 1), 1e-5)
+        m = _FakeScoreModel(logits)
+        with RecordRand() as rr:
+            xd = sampling.Denoiser(graph, noise).update_fn(score_model=m, x=x, t=te, step_size=dt, task="protein_only")
+        out[tag + "_denoise_t"], out[tag + "_denoise_u"], out[tag + "_denoise_out"] = te, rr.log[0][1], xd
+    # Uniform graph, Euler + Analytic + Denoiser
+    V, B, L = 25, 4, 32
+    graph = graph_lib.Uniform(V)
+    noise = noise_lib.GeometricNoise(1e-4, 20.0)
+    x = torch.randint(0, V, (B, L))
+    logits = torch.randn(B, L, V)
+    logits.scatter_(-1, x[..., None], torch.zeros(B, L, 1))
+    t = torch.tensor([0.9, 0.5, 0.2, 0.05])[:, None]
+    dt = 1.0 / 16
+    tag = "u25"
+    out[tag + "_x"], out[tag + "_logits"], out[tag + "_t"], out[tag + "_dt"] = x, logits, t, np.float64(dt)
+    m = _FakeScoreModel(logits)
+    with RecordRand() as rr:
+        xe = quiet(sampling.EulerPredictor(graph, noise).update_fn, score_model=m, x=x, t=t, step_size=dt,
+                   task="protein_only")
+    out[tag + "_euler_u"], out[tag + "_euler_out"] = rr.log[0][1], xe
+    with RecordRand() as rr:
+        xa = sampling.AnalyticPredictor(graph, noise).update_fn(lambda xx, s: logits.exp(), x, t, dt)
+    out[tag + "_analytic_u"], out[tag + "_analytic_out"] = rr.log[0][1], xa
+    te = torch.full((B, 1), 1e-5)
+    m = _FakeScoreModel(logits)
+    with RecordRand() as rr:
+        xd = sampling.Denoiser(graph, noise).update_fn(score_model=m, x=x, t=te, step_size=dt, task="protein_only")
+    out[tag + "_denoise_t"], out[tag + "_denoise_u"], out[tag + "_denoise_out"] = te, rr.log[0][1], xd
+    save("g6_predictor_steps", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G7
+def g7_timestep_embed():
+    torch.manual_seed(107)
+    emb = ref_tf.TimestepEmbedder(128)
+    load_seeded(emb, seed=7)
+    sigma = torch.tensor([1e-3, 0.01, 0.3, 0.69, 2.5, 6.9, 20.0])
+    freq = emb.timestep_embedding(sigma, 256)
+    c = F.silu(emb(sigma))
+    w = torch.randn_like(c)
+    (c * w).sum().backward()
+    out = {"sigma": sigma, "freq": freq, "c": c, "w": w}
+    for n, p in emb.named_parameters():
+        out["grad." + n] = p.grad
+    save("g7_timestep_embed", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G8
+def g8_ddit_block():
+    torch.manual_seed(108)
+    out = {}
+    for tag, D, H, C, B, L in (("d32", 128, 4, 64, 3, 48), ("d64", 128, 2, 64, 2, 80), ("d96", 192, 2, 64, 2, 40)):
+        blk = ref_tf.DDiTBlock(D, H, C, dropout=0.0)
+        load_seeded(blk, seed=8, std=0.05)
+        blk.eval()
+        x = torch.randn(B, L, D, requires_grad=True)
+        c = torch.randn(B, C, requires_grad=True)
+        rot = ref_rotary.Rotary(D // H)
+        cos, sin = rot(x)
+        y = blk(x, (cos, sin), c)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        t = f"flash_{tag}_"
+        out.update({t + "x": x, t + "c": c, t + "y": y, t + "w": w, t + "dx": x.grad, t + "dc": c.grad,
+                    t + "dims": np.array([D, H, C, B, L])})
+        for n, p in blk.named_parameters():
+            out[t + "grad." + n] = p.grad
+    # cross variant (transformers_protlig_cross.py:237-320): batch-axis self-attention quirk Q1 as written,
+    # with and without other_track, with and without key-padding mask
+    D, H, C, B, L, Lo = 64, 2, 32, 3, 20, 12
+    blk = ref_cross.DDiTBlock(D, H, 0.0, C)
+    load_seeded(blk, seed=9, std=0.05)
+    blk.eval()
+    x = torch.randn(B, L, D, requires_grad=True)
+    c = torch.randn(B, C, requires_grad=True)
+    other = torch.randn(B, Lo, D, requires_grad=True)
+    mask = torch.ones(B, Lo, dtype=torch.bool)
+    mask[0, 9:] = False
+    mask[2, 5:] = False
+    rot = ref_rotary.Rotary(D // H)
+    cos, sin = rot(x)
+    t = "cross_"
+    out.update({t + "x": x, t + "c": c, t + "other": other, t + "mask": mask, t + "dims": np.array([D, H, C, B, L, Lo])})
+    y0 = blk(x, (cos, sin), c)
+    out[t + "y_noother"] = y0
+    y1 = blk(x, (cos, sin), c, other_track=other)
+    w = torch.randn_like(y1)
+    out[t + "w"] = w
+    (y1 * w).sum().backward()
+    out.update({t + "y": y1, t + "dx": x.grad.clone(), t + "dc": c.grad.clone(), t + "dother": other.grad.clone()})
+    for n, p in blk.named_parameters():
+        out[t + "grad." + n] = p.grad.clone()
+    y2 = blk(x, (cos, sin), c, other_track=other, other_mask=mask)
+    out[t + "y_masked"] = y2
+    save("g8_ddit_block", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G9
+def g9_cross_attention():
+    torch.manual_seed(109)
+    D, H, B, Lq, Lk = 64, 2, 3, 20, 12
+    layer = ref_cross.CrossAttentionLayer(D, H, dropout=0.0)
+    load_seeded(layer, seed=10, std=0.08)
+    layer.eval()
+    x = torch.randn(B, Lq, D, requires_grad=True)
+    ctx = torch.randn(B, Lk, D, requires_grad=True)
+    mask = torch.ones(B, Lk, dtype=torch.bool)
+    mask[1, 7:] = False
+    out = {"x": x, "ctx": ctx, "mask": mask, "dims": np.array([D, H, B, Lq, Lk])}
+    y = layer(x, ctx)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    out.update({"y": y, "w": w, "dx": x.grad.clone(), "dctx": ctx.grad.clone()})
+    for n, p in layer.named_parameters():
+        out["grad." + n] = p.grad.clone()
+        p.grad = None
+    x.grad = None
+    ctx.grad = None
+    ym = layer(x, ctx, context_mask=mask)
+    (ym * w).sum().backward()
+    out.update({"y_masked": ym, "dx_masked": x.grad.clone(), "dctx_masked": ctx.grad.clone()})
+    save("g9_cross_attention", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G10
+class _KwDrop(torch.nn.Module):
+    """losses.get_loss_fn -> model/utils.py:36 passes prot_seq=/lig_seq=/task= that SEDD.forward does not take."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x, sigma, **kw):
+        return self.m(x, sigma)
+
+
+def _loss_inputs(B, L, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randint(0, V - 1, (B, L), generator=g)
+    t = (1 - 1e-3) * torch.rand(B, generator=g) + 1e-3
+    u = torch.rand(B, L, generator=g)
+    return x0, t, u
+
+
+def g10_sedd_model():
+    out = {}
+    graph = graph_lib.Absorbing(25)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    for tag, cfg, B, L in (("mini", sedd_config(128, 4, 64, 2), 3, 64),
+                           ("mini96", sedd_config(192, 2, 64, 2), 2, 40),
+                           ("tiny", sedd_config(768, 8, 128, 8), 8, 128)):
+        model = ref_tf._SEDD(cfg)
+        load_seeded(model, seed=10)
+        model.eval()
+        x0, t, u = _loss_inputs(B, L, 26, 1000 + len(tag))
+        sigma, dsigma = noise(t)
+        xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 25), x0)
+        logits = quiet(model, xt, sigma)
+        loss_fn = losses.get_loss_fn(noise, graph, train=False)
+        loss = quiet(loss_fn, _KwDrop(model), x0, t=t, perturbed_batch=xt)
+        t_ = tag + "_"
+        out.update({t_ + "x0": x0, t_ + "t": t, t_ + "u": u, t_ + "xt": xt, t_ + "sigma": sigma,
+                    t_ + "logits": logits, t_ + "loss": loss,
+                    t_ + "cfg": np.array([cfg.model.hidden_size, cfg.model.n_heads, cfg.model.cond_dim,
+                                          cfg.model.n_blocks, cfg.tokens])})
+        if tag != "tiny":
+            model.zero_grad()
+            loss.backward()
+            for n, p in model.named_parameters():
+                out[t_ + "grad." + n] = p.grad
+    # KAT-init-loss: untouched reference init -> logits = -log(e^sigma-1) - log(V-1)
+    cfg = sedd_config(128, 4, 64, 2)
+    model = ref_tf._SEDD(cfg).eval()
+    x0, t, u = _loss_inputs(4, 32, 26, 77)
+    sigma, dsigma = noise(t)
+    xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 25), x0)
+    out["init_x0"], out["init_t"], out["init_xt"] = x0, t, xt
+    out["init_logits"] = quiet(model, xt, sigma)
+    out["init_loss"] = quiet(losses.get_loss_fn(noise, graph, train=False), _KwDrop(model), x0, t=t, perturbed_batch=xt)
+    save("g10_sedd_model", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G11
+def cross_config(hidden, heads, cond, blocks, dropout=0.0):
+    return NS(graph=NS(type="absorb"),
+              model=NS(hidden_size=hidden, n_heads=heads, cond_dim=cond, n_blocks=blocks, dropout=dropout,
+                       scale_by_sigma=True, device="cpu"))
+
+
+def g11_cross_model():
+    torch.manual_seed(111)
+    cfg = cross_config(64, 2, 32, 2)
+    model = ref_cross.ProteinLigandDiffusionModel(cfg)
+    load_seeded(model, seed=11, std=0.05)
+    model.eval()
+    B, Lp, Ll = 3, 24, 16
+    gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    p0 = torch.randint(0, 33, (B, Lp))
+    l0 = torch.randint(0, 2362, (B, Ll))
+    t = torch.tensor([0.15, 0.6, 0.93])
+    sigma, dsigma = noise(t)
+    up, ul = torch.rand(B, Lp), torch.rand(B, Ll)
+    move = 1 - (-sigma[:, None]).exp()
+    pt = torch.where(up < move, torch.full_like(p0, 36), p0)
+    lt = torch.where(ul < move, torch.full_like(l0, 2364), l0)
+    out = {"p0": p0, "l0": l0, "t": t, "up": up, "ul": ul, "pt": pt, "lt": lt, "sigma": sigma, "dsigma": dsigma,
+           "cfg": np.array([64, 2, 32, 2])}
+    lp, ll = model(protein_indices=pt, ligand_indices=lt, timesteps=sigma, mode="joint")
+    out["joint_prot_logits"], out["joint_lig_logits"] = lp, ll
+    # calc_loss joint (run_train_protlig_cross_att.py:284-294): Q3 as written, and the per-sample form
+    se_p = gp.score_entropy(lp, sigma[:, None], pt, p0)
+    se_l = gl.score_entropy(ll, sigma[:, None], lt, l0)
+    loss_q3 = (dsigma[:, None] * ((se_p.mean() + se_l.mean()) / 2)).mean()
+    loss_ps = ((dsigma[:, None] * se_p).mean() + (dsigma[:, None] * se_l).mean()) / 2
+    out["joint_loss_q3"], out["joint_loss_persample"] = loss_q3, loss_ps
+    model.zero_grad()
+    loss_q3.backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            out["joint_grad." + n] = p.grad.clone()
+    out["prot_only_logits"] = model(protein_indices=pt, timesteps=sigma, mode="protein_only")
+    out["lig_only_logits"] = model(ligand_indices=lt, timesteps=sigma, mode="ligand_only")
+    out["lig_given_prot_logits"] = model(protein_indices=p0, ligand_indices=lt, timesteps=sigma,
+                                         mode="ligand_given_protein")
+    out["prot_given_lig_logits"] = model(protein_indices=pt, ligand_indices=l0, timesteps=sigma,
+                                         mode="protein_given_ligand")
+    save("g11_cross_model", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G12
+def g12_train_trajectory():
+    cfg = sedd_config(128, 4, 64, 2)
+    model = ref_tf._SEDD(cfg)
+    load_seeded(model, seed=12)
+    graph = graph_lib.Absorbing(25)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    params = list(model.parameters()) + list(noise.parameters())
+    opt = torch.optim.AdamW(params, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.9999)
+    loss_fn = losses.get_loss_fn(noise, graph, train=True)
+    wrapped = _KwDrop(model)
+    B, L, steps, warmup, lr = 4, 64, 4, 2, 3e-4
+    out = {"cfg": np.array([128, 4, 64, 2, 25]), "hyper": np.array([lr, 0.9, 0.999, 1e-8, 0.0, warmup, 1.0, 0.9999])}
+    ls, gns = [], []
+    for s in range(steps):
+        x0, t, u = _loss_inputs(B, L, 26, 500 + s)
+        sigma, _ = noise(t)
+        xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 25), x0)
+        out[f"x0_{s}"], out[f"t_{s}"], out[f"xt_{s}"] = x0, t, xt
+        loss = quiet(loss_fn, wrapped, x0, t=t, perturbed_batch=xt)
+        opt.zero_grad()
+        loss.backward()
+        # optimize_fn (losses.py:60-69) without the GradScaler (fp32, scale == 1)
+        for g in opt.param_groups:
+            g["lr"] = lr * np.minimum((s + 1) / warmup, 1.0)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+        ema.update(model.parameters())
+        ls.append(loss.detach())
+        gns.append(gn.detach())
+    out["losses"], out["grad_norms"] = torch.stack(ls), torch.stack(gns)
+    sd = model.state_dict()
+    out["final.blocks.0.attn_qkv.weight"] = sd["blocks.0.attn_qkv.weight"]
+    out["final.output_layer.linear.bias"] = sd["output_layer.linear.bias"]
+    out["final.vocab_embed.embedding.weight"] = sd["vocab_embed.embedding.weight"]
+    names = [n for n, _ in model.named_parameters()]
+    i = names.index("blocks.0.attn_qkv.weight")
+    out["ema.blocks.0.attn_qkv.weight"] = ema.shadow_params[i]
+    out["ema_num_updates"] = np.array(ema.num_updates)
+    save("g12_train_trajectory", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G13
+class _SamplerModel(torch.nn.Module):
+    """Adapts mini _SEDD to the keyword call of EulerPredictor/Denoiser (sampling.py:65-76,111-122)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, protein_indices=None, ligand_indices=None, timesteps=None, mode=None):
+        return self.m(protein_indices, timesteps)
+
+
+def g13_pc_sampler():
+    cfg = sedd_config(128, 4, 64, 2)
+    model = ref_tf._SEDD(cfg)
+    load_seeded(model, seed=13, std=0.1)
+    graph = graph_lib.Absorbing(25)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    B, L, steps = 3, 32, 6
+    out = {"cfg": np.array([128, 4, 64, 2, 25]), "dims": np.array([B, L, steps])}
+    torch.manual_seed(113)
+    sampler = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, denoise=True, eps=1e-5)
+    with RecordRand() as rr:
+        x = quiet(sampler, _SamplerModel(model), "protein_only")
+    out["euler_out"] = x
+    out["euler_u"] = torch.stack([r for _, r in rr.log[:steps]])
+    out["euler_u_denoise"] = rr.log[steps][1]
+    # Analytic predictor through the same loop (upstream signature; the reference loop cannot call it, Q5):
+    # replicate get_pc_sampler's loop (sampling.py:157-173) around AnalyticPredictor.update_fn / Denoiser.
+    torch.manual_seed(114)
+    pred = sampling.AnalyticPredictor(graph, noise)
+    den = sampling.Denoiser(graph, noise)
+    model.eval()
+    score_fn = lambda xx, s: quiet(model, xx, s.reshape(-1)).exp()  # noqa: E731
+    xs = []
+    with torch.no_grad(), RecordRand() as rr:
+        x = graph.sample_limit(B, L)
+        timesteps = torch.linspace(1, 1e-5, steps + 1)
+        dt = (1 - 1e-5) / steps
+        for i in range(steps):
+            t = timesteps[i] * torch.ones(B, 1)
+            x = pred.update_fn(score_fn, x, t, dt)
+            xs.append(x.clone())
+        t = timesteps[-1] * torch.ones(B, 1)
+        x = quiet(den.update_fn, score_model=_SamplerModel(model), x=x, t=t, step_size=dt, task="protein_only")
+    out["analytic_out"] = x
+    out["analytic_steps"] = torch.stack(xs)
+    out["analytic_u"] = torch.stack([r for _, r in rr.log[:steps]])
+    out["analytic_u_denoise"] = rr.log[steps][1]
+    save("g13_pc_sampler", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G14
+def g14_ema():
+    torch.manual_seed(114)
+    lin = torch.nn.Linear(5, 7)
+    ema = ExponentialMovingAverage(lin.parameters(), decay=0.999)
+    out = {"w0": lin.weight.detach().clone(), "b0": lin.bias.detach().clone()}
+    ws, bs = [], []
+    for s in range(12):
+        with torch.no_grad():
+            for p in lin.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        ws.append(lin.weight.detach().clone())
+        bs.append(lin.bias.detach().clone())
+        ema.update(lin.parameters())
+    out["ws"], out["bs"] = torch.stack(ws), torch.stack(bs)
+    out["shadow_w"], out["shadow_b"] = ema.shadow_params[0], ema.shadow_params[1]
+    out["num_updates"] = np.array(ema.num_updates)
+    save("g14_ema", **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    for fn in (g1_noise, g2_sample_transition, g3_score_entropy, g4_graph_ops, g5_sample_categorical,
+               g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
+               g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema):
+        if only and not any(fn.__name__.startswith(o) for o in only):
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
