@@ -1,0 +1,202 @@
+/* libsedd_hip — C ABI of the MI355X (gfx950) SEDD hot path.
+ *
+ * The reference (architvasan/protein_lig_sedd) is pure Python and has no FFI of its own; its seams are Python
+ * call sites into third-party native ops (flash-attn, cuBLAS via nn.Linear, TorchScript fusions, ATen
+ * elementwise).  Each entry point below replaces one such call site; the comment above it cites the reference
+ * file:line whose arithmetic it reproduces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees or synchronises
+ *    (exception: none in this header), launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - tensors are dense row-major unless strides are given; index tensors are int64 (torch.long) as in the
+ *    reference; per-batch scalars (sigma, dsigma, ...) are fp32 arrays of length B; M = B*L rows, row r belongs
+ *    to batch r / L.
+ *  - `dtype` arguments take SEDD_F32 or SEDD_BF16 and describe the activation/logit element type; reductions
+ *    and all transcendental maths are fp32.
+ *  - return value: 0 on success, <0 = sedd_status; sedd_last_error() gives a thread-local message.
+ *  - re-entrant; no mutable global state.
+ */
+#ifndef SEDD_HIP_H
+#define SEDD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEDD_ABI_VERSION 1
+
+typedef void* sedd_stream_t; /* hipStream_t */
+
+enum sedd_status { SEDD_OK = 0, SEDD_ERR_BAD_ARG = -1, SEDD_ERR_UNSUPPORTED_SHAPE = -2, SEDD_ERR_LAUNCH = -3 };
+enum sedd_dtype { SEDD_F32 = 0, SEDD_BF16 = 1 };
+enum sedd_graph { SEDD_ABSORB = 0, SEDD_UNIFORM = 1 };
+/* predictor step kinds: sampling/sampling.py:59-80 (Euler), :88-99 (Analytic), :102-132 (Denoiser) */
+enum sedd_step { SEDD_STEP_EULER = 0, SEDD_STEP_ANALYTIC = 1, SEDD_STEP_DENOISE = 2 };
+/* GEMM epilogues */
+enum sedd_epilogue { SEDD_EPI_NONE = 0, SEDD_EPI_BIAS = 1, SEDD_EPI_BIAS_GELU = 2 };
+
+int sedd_abi_version(void);
+const char* sedd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ graph ops
+ * processing/graph_lib.py. V = graph.dim (absorbing: tokens+1, mask id V-1). */
+
+/* Absorbing.sample_transition (graph_lib.py:258-262) / Uniform.sample_transition (:156-160):
+ * xt = (u < 1 - exp(-sigma_b)) ? (absorb: V-1 | uniform: r) : x0.  u fp32 [M]; r int64 [M] (uniform only). */
+int sedd_sample_transition(int graph, const int64_t* x0, const float* sigma, const float* u, const int64_t* r,
+                           int64_t* xt, int64_t M, int64_t L, int V, sedd_stream_t stream);
+
+/* Absorbing.score_entropy (graph_lib.py:274-314) / Uniform.score_entropy (:170-197). out fp32 [M].
+ * If dscore != NULL also writes d(sum_r gw[r/L]*out[r]) / dscore (same dtype as score) — the fused
+ * loss-forward+backward of losses.py:27-29 where gw_b = dsigma_b / M. */
+int sedd_score_entropy_fwd(int graph, const void* score, int dtype, const float* sigma, const int64_t* x,
+                           const int64_t* x0, float* out, void* dscore, const float* gw, int64_t M, int64_t L,
+                           int V, sedd_stream_t stream);
+/* autograd backward of the above for an arbitrary upstream gradient gout fp32 [M]. */
+int sedd_score_entropy_bwd(int graph, const void* score, int dtype, const float* sigma, const int64_t* x,
+                           const int64_t* x0, const float* gout, void* dscore, int64_t M, int64_t L, int V,
+                           sedd_stream_t stream);
+
+/* utils/catsample.py:10-13 with the uniform noise passed in: out = argmax_j p_j / (1e-10 - log(u_j + 1e-10)),
+ * first index wins ties. p has `dtype`, u fp32, both [M, V]. */
+int sedd_gumbel_argmax(const void* p, int dtype, const float* u, int64_t* out, int64_t M, int V,
+                       sedd_stream_t stream);
+
+/* One fused predictor update (sampling/sampling.py:61-80, :90-99, :107-132 with graph_lib.py:79-96, :162-165,
+ * :226-234, :264-269 and catsample.py:12-13): log-score -> exp -> reverse rate | staggered score x transposed
+ * transition -> Gumbel arg-max.  coef fp32 [B]: Euler: dt*dsigma_b; Analytic: sigma(t)-sigma(t-dt); Denoise:
+ * sigma(t).  u fp32 [M, Vu], Vu = V, except Denoise on the absorbing graph where Vu = V-1 (mask column dropped). */
+int sedd_predictor_step(int graph, int step, const void* logscore, int dtype, const int64_t* x, const float* coef,
+                        const float* u, int64_t* xnew, int64_t M, int64_t L, int V, sedd_stream_t stream);
+
+/* Stand-alone Graph methods (for Graph-API parity; the predictor kernel above fuses them).  All outputs fp32
+ * [M, V].  graph_lib.py:218-221/:139-145 (transp_rate), :79-93 (reverse_rate), :264-269/:162-165
+ * (staggered_score), :226-234/:147-154 (transp_transition). score fp32 [M,V]; sig fp32 [B]. */
+int sedd_transp_rate(int graph, const int64_t* x, float* out, int64_t M, int V, sedd_stream_t stream);
+int sedd_reverse_rate(int graph, const int64_t* x, const float* score, float* out, int64_t M, int V,
+                      sedd_stream_t stream);
+int sedd_staggered_score(int graph, const float* score, const float* dsigma, float* out, int64_t M, int64_t L,
+                         int V, sedd_stream_t stream);
+int sedd_transp_transition(int graph, const int64_t* x, const float* sigma, float* out, int64_t M, int64_t L,
+                           int V, sedd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ model: pointwise */
+
+/* model/transformer.py:70-89: out[b] = [cos(sigma_b f_k), sin(sigma_b f_k)], f_k = exp(-ln(1e4) k / half). */
+int sedd_timestep_embedding(const float* sigma, float* out, int B, int dim, sedd_stream_t stream);
+/* SiLU forward / backward (transformer.py:62-66, :285), fp32, n elements. dx = dy * silu'(x). */
+int sedd_silu_fwd(const float* x, float* y, int64_t n, sedd_stream_t stream);
+int sedd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, sedd_stream_t stream);
+
+/* EmbeddingLayer (transformer.py:193-218): out[r] = table[idx[r]] (fp32 [V, D]). */
+int sedd_embedding_fwd(const float* table, const int64_t* idx, float* out, int64_t M, int D, int V,
+                       sedd_stream_t stream);
+/* dtable[idx[r]] += dout[r] (dtable fp32 [V, D], accumulated into). */
+int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t M, int D, int V,
+                       sedd_stream_t stream);
+
+/* LayerNorm (transformer.py:30-38, fp32, eps 1e-5, scale w, no bias) fused with modulate_fused
+ * (fused_add_dropout_scale.py:33-34): y = LN(x)*w*(1+scale_b)+shift_b.  x fp32 [M, D]; shift/scale are rows of
+ * the adaLN output: element (b, j) at shift[b*mod_stride + j] in `mod_dtype`; y in `out_dtype`;
+ * mean/rstd fp32 [M] saved for backward.  shift == NULL (and scale == NULL) gives plain LN(x)*w (+ bias b if
+ * non-NULL: the affine nn.LayerNorm of transformers_protlig_cross.py:114). */
+int sedd_ln_modulate_fwd(const float* x, const float* w, const float* bias, const void* shift, const void* scale,
+                         int mod_dtype, int64_t mod_stride, void* y, int out_dtype, float* mean, float* rstd,
+                         int64_t M, int64_t L, int D, sedd_stream_t stream);
+/* backward: dx (fp32 [M,D]) is ACCUMULATED into (dx += ...) when accumulate != 0, else written.
+ * Partial column sums go to caller workspace ws fp32 [3, nchunk, D] (nchunk = sedd_ln_bwd_chunks(M, L)), in the
+ * order d(w), d(shift)/d(bias), d(scale); chunks never straddle a batch element so that
+ * sedd_ln_modulate_bwd_reduce can fold them into dw[D] (+=), dshift[B, .] and dscale[B, .] (fp32, written with
+ * stride dmod_stride). */
+int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L);
+int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                         int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
+                         int accumulate, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
+int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float* dscale, int64_t dmod_stride,
+                                int64_t M, int64_t L, int D, sedd_stream_t stream);
+
+/* bias_dropout_add_scale (fused_add_dropout_scale.py:13-48), bias == None at every reference call site:
+ * out = residual + gate_b * (a * keep / (1-p)).  residual/out fp32 [M,D], a in `a_dtype`, gate rows as in
+ * ln_modulate; keep: optional uint8 [M,D] dropout keep-mask (NULL = inference / p = 0), inv_keep = 1/(1-p). */
+int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, const void* gate, int mod_dtype,
+                           int64_t mod_stride, const uint8_t* keep, float inv_keep, float* out, int64_t M,
+                           int64_t L, int D, sedd_stream_t stream);
+/* backward: da = dout * gate_b * keep*inv_keep (a_dtype); per-chunk partial sums of dgate = sum_l dout*a*keep*inv
+ * to ws fp32 [nchunk, D] (same chunking as sedd_ln_bwd_chunks), folded by sedd_gate_residual_bwd_reduce. */
+int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
+                           int64_t mod_stride, const uint8_t* keep, float inv_keep, void* da, float* ws,
+                           int64_t M, int64_t L, int D, sedd_stream_t stream);
+int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L, int D,
+                                  sedd_stream_t stream);
+
+/* Rotary (model/rotary.py:13-51): in-place NeoX rotation of the Q and K slots of qkv [B, L, 3, H, d];
+ * conj != 0 applies the transposed rotation (backward).  cos/sin are computed in-kernel from
+ * inv_freq_j = 1e4^(-2j/d) in fp32 (position = l). */
+int sedd_rotary_qkv(void* qkv, int dtype, int B, int L, int H, int d, int conj, sedd_stream_t stream);
+
+/* GELU(tanh) forward/backward (transformer.py:138): g = gelu(u); du = dg * gelu'(u). */
+int sedd_gelu_fwd(const void* u, void* g, int dtype, int64_t n, sedd_stream_t stream);
+int sedd_gelu_bwd(const void* u, const void* dg, void* du, int dtype, int64_t n, sedd_stream_t stream);
+
+/* Output epilogue of SEDD.forward (transformer.py:313-322): in place on logits [M, V]:
+ * x -= log(E(sigma_b)) (cast to dtype) + log(V-1) when scale_by_sigma; x[r, idx[r]] = 0. */
+int sedd_logits_epilogue(void* logits, int dtype, const float* sigma, const int64_t* idx, int scale_by_sigma,
+                         int64_t M, int64_t L, int V, sedd_stream_t stream);
+/* its backward: dlogits[r, idx[r]] = 0 in place. */
+int sedd_logits_epilogue_bwd(void* dlogits, int dtype, const int64_t* idx, int64_t M, int V, sedd_stream_t stream);
+
+/* Column sums: out[j] (+)= sum_r a[r, j]  (bias gradients); a [M, N] with row stride lda; out fp32 [N]. */
+int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, int accumulate, int64_t M, int N,
+                sedd_stream_t stream);
+/* out[N, M] = a[M, N]^T with optional dtype conversion (operand re-layout for the wgrad/dgrad GEMMs). */
+int sedd_transpose(const void* a, int a_dtype, int64_t lda, void* out, int out_dtype, int64_t ldo, int64_t M,
+                   int64_t N, sedd_stream_t stream);
+/* elementwise cast fp32 <-> bf16, n elements. */
+int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, sedd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------- GEMM
+ * nn.Linear (transformer.py:125-134,140,225,229; transformers_protlig_cross.py:250-268):
+ * C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (GELU-tanh), both operands K-contiguous ("NT").
+ * in_dtype: SEDD_BF16 (v_mfma_f32_16x16x32_bf16) or SEDD_F32 (exact-fp32 v_mfma_f32_32x32x2_f32);
+ * fp32 accumulation; C in out_dtype; accumulate != 0: C += (fp32 C only; weight-gradient accumulation).
+ * bias fp32 or NULL.  For SEDD_EPI_BIAS_GELU, pre (may be NULL) receives the pre-activation (out_dtype).
+ * Requirements: K % 8 == 0 (bf16) / K % 4 == 0 (fp32), lda/ldb multiples of the same, 16-byte aligned bases. */
+int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                 int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
+                 int64_t K, sedd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ attention
+ * The flash-attn boundary (transformer.py:172-183: flash_attn_varlen_qkvpacked_func, non-causal, no dropout,
+ * softmax scale d^-1/2, equal-length sequences) and nn.MultiheadAttention's core
+ * (transformers_protlig_cross.py:135-138, :305) as ONE strided kernel family: element (b, l, h, :) of q at
+ * q + b*q_bs + l*q_ls + h*d, likewise k, v (k/v share strides), o at o + b*o_bs + l*o_ls + h*d (head dim
+ * contiguous).  key_mask: optional uint8 [B, Lk], 1 = attend (the inverse of key_padding_mask).
+ * lse fp32 [B, H, Lq] is written for backward.  d in {32, 64, 96, 128}. */
+int sedd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* key_mask,
+                  int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
+                  int64_t kv_ls, int64_t o_bs, int64_t o_ls, sedd_stream_t stream);
+/* backward: dq/dk/dv written with the strides of q/k/v; delta fp32 [B, H, Lq] is caller workspace. */
+int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                  const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta, int dtype, int B, int H,
+                  int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs,
+                  int64_t o_ls, sedd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------- optimiser / EMA
+ * One pass over the flat fp32 parameter buffer: gradient clip coefficient (losses.py:65-66) -> AdamW
+ * (losses.py:39-41; torch.optim.AdamW) -> EMA shadow update (model/ema.py:32-52) -> bf16 compute copy.
+ * clip_coef: device scalar fp32 (min(1, max_norm/(norm+1e-6))), grad_scale multiplies g first (1/world etc.).
+ * ema/p_bf16 may be NULL.  step is 1-based. */
+int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                        const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float ema_decay, int64_t n, sedd_stream_t stream);
+/* out[0] = sum_i g[i]^2 (fp32, deterministic two-stage); ws fp32 [1024] caller workspace.
+ * Then, when max_norm > 0: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)). */
+int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float max_norm, float* ws, float* out,
+                    sedd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEDD_HIP_H */

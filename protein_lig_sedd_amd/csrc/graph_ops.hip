@@ -1,0 +1,435 @@
+// Bandwidth-bound token-graph kernels: corruption, score-entropy loss (+gradient), Gumbel arg-max and the fused
+// Euler / Analytic / Denoiser predictor updates.  Reference: protlig_dd/processing/graph_lib.py,
+// protlig_dd/sampling/sampling.py, protlig_dd/utils/catsample.py (cited per kernel).
+//
+// Layout: score / log-score / noise rows are [M, V] row-major; a row is owned by a G-lane sub-group of a wave
+// (G = 8/16/32/64 >= min(V, 64)), lanes stride over the vocab axis so consecutive lanes touch consecutive
+// addresses and consecutive groups consecutive rows (fully coalesced for V <= 64); reductions over the vocab
+// axis are xor-shuffles inside the group.  Everything here is HBM-bound: one read of every input byte, one
+// write of every output byte, fp32 maths.
+//
+// Floating-point contraction is off in this file so that every product/sum rounds exactly like the reference's
+// op-by-op torch arithmetic (needed for bit-exact sampled indices).
+#include "common.h"
+#pragma clang fp contract(off)
+
+#define TPB 256
+
+template <int G> struct GroupIdx {
+    int lane;
+    int64_t first, stride;
+    __device__ GroupIdx() {
+        lane = threadIdx.x & (G - 1);
+        first = (int64_t)blockIdx.x * (TPB / G) + (threadIdx.x / G);
+        stride = (int64_t)gridDim.x * (TPB / G);
+    }
+};
+
+__device__ __forceinline__ float gumbel_ratio(float p, float u) {
+    // catsample.py:12-13: probs / (1e-10 - (u + 1e-10).log())
+    return p / (1e-10f - logf(u + 1e-10f));
+}
+
+// ------------------------------------------------------------------------------------- sample_transition
+// graph_lib.py:258-262 (absorbing), :156-160 (uniform)
+__global__ void __launch_bounds__(TPB) sample_transition_kernel(int graph, const int64_t* __restrict__ x0,
+                                                               const float* __restrict__ sigma,
+                                                               const float* __restrict__ u,
+                                                               const int64_t* __restrict__ r,
+                                                               int64_t* __restrict__ xt, int64_t M, int64_t L,
+                                                               int V) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M; i += (int64_t)gridDim.x * TPB) {
+        const float move_chance = 1.0f - expf(-sigma[i / L]);
+        const bool move = u[i] < move_chance;
+        const int64_t tgt = graph == SEDD_ABSORB ? (int64_t)(V - 1) : r[i];
+        xt[i] = move ? tgt : x0[i];
+    }
+}
+
+extern "C" int sedd_sample_transition(int graph, const int64_t* x0, const float* sigma, const float* u,
+                                      const int64_t* r, int64_t* xt, int64_t M, int64_t L, int V,
+                                      sedd_stream_t stream) {
+    SEDD_CHECK_ARG(graph == SEDD_ABSORB || graph == SEDD_UNIFORM, "sample_transition: unknown graph %d", graph);
+    SEDD_CHECK_ARG(M == 0 || (x0 && sigma && u && xt), "sample_transition: null pointer");
+    SEDD_CHECK_ARG(M == 0 || graph == SEDD_ABSORB || r, "sample_transition: uniform graph needs r");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 0 && M % L == 0, "sample_transition: bad sizes M=%ld L=%ld V=%d", (long)M,
+                   (long)L, V);
+    if (M == 0) return SEDD_OK;
+    hipLaunchKernelGGL(sample_transition_kernel, dim3(sedd_grid_for(M, TPB)), dim3(TPB), 0, (hipStream_t)stream,
+                       graph, x0, sigma, u, r, xt, M, L, V);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ score entropy
+// Absorbing: graph_lib.py:274-314.  Uniform: graph_lib.py:170-197.  gout == nullptr: gradient weight is gw[b]
+// (fused loss path) ; dscore == nullptr: forward only ; out == nullptr: backward only.
+template <typename T, int G>
+__global__ void __launch_bounds__(TPB) score_entropy_kernel(int graph, const T* __restrict__ score,
+                                                            const float* __restrict__ sigma,
+                                                            const int64_t* __restrict__ x,
+                                                            const int64_t* __restrict__ x0, float* __restrict__ out,
+                                                            T* __restrict__ dscore, const float* __restrict__ gw,
+                                                            const float* __restrict__ gout, int64_t M, int64_t L,
+                                                            int V) {
+    GroupIdx<G> g;
+    for (int64_t row = g.first; row < M; row += g.stride) {
+        const int64_t xi = x[row];
+        const float sig = sigma[row / L];
+        const float es = esigm1f(sig);
+        const T* srow = score + row * V;
+        T* drow = dscore ? dscore + row * V : nullptr;
+        float w = 0.f;
+        if (drow) w = gout ? gout[row] : gw[row / L];
+        if (graph == SEDD_ABSORB) {
+            if (xi != V - 1) {  // unmasked token: zero loss, zero gradient
+                if (out && g.lane == 0) out[row] = 0.f;
+                if (drow)
+                    for (int j = g.lane; j < V; j += G) drow[j] = from_f32<T>(0.f);
+                continue;
+            }
+            int64_t o = x0[row];
+            o = o < 0 ? 0 : (o > V - 1 ? V - 1 : o);
+            const float ratio = 1.0f / es;
+            float pos = 0.f, so = 0.f;
+            for (int j = g.lane; j < V; j += G) {
+                const float s = to_f32<T>(srow[j]);
+                const float e = j < V - 1 ? expf(s) : 0.f;
+                pos += e;
+                if (j == o) so = s;
+                if (drow) drow[j] = from_f32<T>(w * (e - (j == o ? ratio : 0.f)));
+            }
+            pos = group_sum<G>(pos);
+            so = group_sum<G>(so);
+            if (out && g.lane == 0) out[row] = pos - ratio * so + ratio * (logf(ratio) - 1.0f);
+        } else {
+            const float Vf = (float)V;
+            const int64_t o = x0[row];
+            const float ratio = 1.0f - Vf / (es + Vf);
+            const bool same = xi == o;
+            float ssum = 0.f, esum = 0.f, sx = 0.f, so = 0.f;
+            for (int j = g.lane; j < V; j += G) {
+                const float s = to_f32<T>(srow[j]);
+                const float e = expf(s);
+                ssum += s;
+                esum += e;
+                if (j == xi) sx = s;
+                if (j == o) so = s;
+                if (drow) {
+                    // d pos = (e^s_j - [j==x] e^s_x)/V ; d neg0 = (1 - [j==x])/V
+                    const float notx = j == xi ? 0.f : 1.f;
+                    const float dpos = notx * e / Vf;
+                    const float dneg0 = notx / Vf;
+                    const float dneg = same ? ratio * dneg0 : (j == o ? 1.0f / es : 0.f) + dneg0;
+                    drow[j] = from_f32<T>(w * (dpos - dneg));
+                }
+            }
+            ssum = group_sum<G>(ssum);
+            esum = group_sum<G>(esum);
+            sx = group_sum<G>(sx);
+            so = group_sum<G>(so);
+            if (out && g.lane == 0) {
+                float neg = ssum / Vf - sx / Vf;
+                neg = same ? ratio * neg : so / es + neg;
+                const float lr = logf(ratio);
+                const float cst = same ? (Vf - 1.0f) / Vf * ratio * (lr - 1.0f)
+                                       : ((-lr - 1.0f) / ratio - (Vf - 2.0f)) / Vf;
+                const float pos = esum / Vf - expf(sx) / Vf;
+                out[row] = pos - neg + cst;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_score_entropy(int graph, const void* score, const float* sigma, const int64_t* x,
+                                const int64_t* x0, float* out, void* dscore, const float* gw, const float* gout,
+                                int64_t M, int64_t L, int V, hipStream_t st) {
+    SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((score_entropy_kernel<T, G>), dim3(sedd_grid_for(M, TPB / G)),
+                                              dim3(TPB), 0, st, graph, (const T*)score, sigma, x, x0, out,
+                                              (T*)dscore, gw, gout, M, L, V));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+static int check_se_args(int graph, const void* score, int dtype, const float* sigma, const int64_t* x,
+                         const int64_t* x0, int64_t M, int64_t L, int V) {
+    SEDD_CHECK_ARG(graph == SEDD_ABSORB || graph == SEDD_UNIFORM, "score_entropy: unknown graph %d", graph);
+    SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "score_entropy: unknown dtype %d", dtype);
+    SEDD_CHECK_ARG(M == 0 || (score && sigma && x && x0), "score_entropy: null pointer");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "score_entropy: bad sizes M=%ld L=%ld V=%d", (long)M,
+                   (long)L, V);
+    return SEDD_OK;
+}
+
+extern "C" int sedd_score_entropy_fwd(int graph, const void* score, int dtype, const float* sigma,
+                                      const int64_t* x, const int64_t* x0, float* out, void* dscore,
+                                      const float* gw, int64_t M, int64_t L, int V, sedd_stream_t stream) {
+    int rc = check_se_args(graph, score, dtype, sigma, x, x0, M, L, V);
+    if (rc) return rc;
+    SEDD_CHECK_ARG(M == 0 || out, "score_entropy_fwd: out is null");
+    SEDD_CHECK_ARG(!dscore || gw, "score_entropy_fwd: dscore requested without gw");
+    if (M == 0) return SEDD_OK;
+    if (dtype == SEDD_F32)
+        return launch_score_entropy<float>(graph, score, sigma, x, x0, out, dscore, gw, nullptr, M, L, V,
+                                           (hipStream_t)stream);
+    return launch_score_entropy<bf16_t>(graph, score, sigma, x, x0, out, dscore, gw, nullptr, M, L, V,
+                                        (hipStream_t)stream);
+}
+
+extern "C" int sedd_score_entropy_bwd(int graph, const void* score, int dtype, const float* sigma,
+                                      const int64_t* x, const int64_t* x0, const float* gout, void* dscore,
+                                      int64_t M, int64_t L, int V, sedd_stream_t stream) {
+    int rc = check_se_args(graph, score, dtype, sigma, x, x0, M, L, V);
+    if (rc) return rc;
+    SEDD_CHECK_ARG(M == 0 || (gout && dscore), "score_entropy_bwd: null pointer");
+    if (M == 0) return SEDD_OK;
+    if (dtype == SEDD_F32)
+        return launch_score_entropy<float>(graph, score, sigma, x, x0, nullptr, dscore, nullptr, gout, M, L, V,
+                                           (hipStream_t)stream);
+    return launch_score_entropy<bf16_t>(graph, score, sigma, x, x0, nullptr, dscore, nullptr, gout, M, L, V,
+                                        (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------ gumbel argmax
+template <typename T, int G>
+__global__ void __launch_bounds__(TPB) gumbel_argmax_kernel(const T* __restrict__ p, const float* __restrict__ u,
+                                                            int64_t* __restrict__ out, int64_t M, int V) {
+    GroupIdx<G> g;
+    for (int64_t row = g.first; row < M; row += g.stride) {
+        const T* prow = p + row * V;
+        const float* urow = u + row * V;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = g.lane; j < V; j += G) {
+            const float v = gumbel_ratio(to_f32<T>(prow[j]), urow[j]);
+            if (argmax_better(v, j, bv, bi)) { bv = v; bi = j; }
+        }
+        group_argmax<G>(bv, bi);
+        if (g.lane == 0) out[row] = bi;
+    }
+}
+
+extern "C" int sedd_gumbel_argmax(const void* p, int dtype, const float* u, int64_t* out, int64_t M, int V,
+                                  sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "gumbel_argmax: unknown dtype %d", dtype);
+    SEDD_CHECK_ARG(M == 0 || (p && u && out), "gumbel_argmax: null pointer");
+    SEDD_CHECK_ARG(M >= 0 && V > 0, "gumbel_argmax: bad sizes M=%ld V=%d", (long)M, V);
+    if (M == 0) return SEDD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEDD_F32) {
+        SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((gumbel_argmax_kernel<float, G>),
+                                                  dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st,
+                                                  (const float*)p, u, out, M, V));
+    } else {
+        SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((gumbel_argmax_kernel<bf16_t, G>),
+                                                  dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st,
+                                                  (const bf16_t*)p, u, out, M, V));
+    }
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ------------------------------------------------------------------------------------- fused predictor step
+// Euler (sampling.py:61-80): p = onehot(x) + dt*dsigma * reverse_rate(x, exp(logscore))   (graph_lib.py:79-96)
+// Analytic (sampling.py:90-99) / Denoiser (:107-132): p = staggered_score(exp(logscore), ds) *
+// transp_transition(x, ds) (graph_lib.py:264-269, :226-234 | :162-165, :147-154), Denoiser drops the mask column.
+// then catsample.py:12-13.  Unmasked rows of the absorbing graph are fixed points (SURVEY section 4
+// KAT-unmasked-fixed-point): p is a one-hot at x, so neither the row's scores nor its noise are read.
+template <typename T, int G>
+__global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step, const T* __restrict__ ls,
+                                                             const int64_t* __restrict__ x,
+                                                             const float* __restrict__ coef,
+                                                             const float* __restrict__ u,
+                                                             int64_t* __restrict__ xnew, int64_t M, int64_t L,
+                                                             int V) {
+    GroupIdx<G> g;
+    const int m = V - 1;
+    const int Vu = (graph == SEDD_ABSORB && step == SEDD_STEP_DENOISE) ? V - 1 : V;
+    for (int64_t row = g.first; row < M; row += g.stride) {
+        const int64_t xi64 = x[row];
+        const int xi = (int)xi64;
+        const float cf = coef[row / L];
+        const T* lrow = ls + row * V;
+        const float* urow = u + row * Vu;
+        if (graph == SEDD_ABSORB && xi != m) {
+            int64_t res = xi64;
+            if (step != SEDD_STEP_EULER) {
+                // p_x = (s_x e^{ds}) * e^{-ds}; every other entry is (+-)0, so x wins unless p_x underflowed to 0
+                const float pi = (expf(to_f32<T>(lrow[xi])) * expf(cf)) * expf(-cf);
+                res = (pi > 0.f || pi != pi) ? xi64 : 0;
+            }
+            if (g.lane == 0) xnew[row] = res;
+            continue;
+        }
+        // pass 1: sum of scores
+        float ssum = 0.f;
+        for (int j = g.lane; j < V; j += G) {
+            const float s = expf(to_f32<T>(lrow[j]));
+            bool inc;
+            if (step == SEDD_STEP_EULER) inc = j != xi;  // reverse_rate zeroes the diagonal before summing
+            else inc = true;                              // staggered_score sums every column
+            if (graph == SEDD_UNIFORM && step == SEDD_STEP_EULER) ssum += inc ? (1.0f / (float)V) * s : 0.f;
+            else ssum += inc ? s : 0.f;
+        }
+        ssum = group_sum<G>(ssum);
+        float e_p = 0.f, e_n = 0.f, one_m_en = 0.f, extra = 0.f, a_u = 0.f, tval = 0.f, tdiag = 0.f;
+        if (step != SEDD_STEP_EULER) {
+            e_p = expf(cf);
+            e_n = expf(-cf);
+            one_m_en = 1.0f - e_n;
+            if (graph == SEDD_ABSORB) {
+                extra = (1.0f - e_p) * ssum;
+            } else {
+                a_u = (e_n - 1.0f) / ((float)V * e_n);
+                tval = (1.0f * one_m_en) / (float)V;
+                float ts = 0.f;
+                for (int j = g.lane; j < V; j += G) ts += j != xi ? tval : 0.f;
+                tdiag = 1.0f - group_sum<G>(ts);
+            }
+        }
+        // pass 2: probabilities, Gumbel ratio, arg-max
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = g.lane; j < Vu; j += G) {
+            const float s = expf(to_f32<T>(lrow[j]));
+            float p;
+            if (step == SEDD_STEP_EULER) {
+                float rj;
+                if (graph == SEDD_ABSORB) rj = j == xi ? -ssum : s;  // row is masked here: transp_rate = 1 off-diag
+                else rj = j == xi ? -ssum : (1.0f / (float)V) * s;
+                p = (j == xi ? 1.0f : 0.f) + cf * rj;
+            } else if (graph == SEDD_ABSORB) {
+                float stag = s * e_p;
+                if (j == m) stag += extra;
+                const float tr = j == m ? e_n + one_m_en : one_m_en;
+                p = stag * tr;
+            } else {
+                const float stag = a_u * ssum + s / e_n;
+                p = stag * (j == xi ? tdiag : tval);
+            }
+            const float v = gumbel_ratio(p, urow[j]);
+            if (argmax_better(v, j, bv, bi)) { bv = v; bi = j; }
+        }
+        group_argmax<G>(bv, bi);
+        if (g.lane == 0) xnew[row] = bi;
+    }
+}
+
+extern "C" int sedd_predictor_step(int graph, int step, const void* logscore, int dtype, const int64_t* x,
+                                   const float* coef, const float* u, int64_t* xnew, int64_t M, int64_t L, int V,
+                                   sedd_stream_t stream) {
+    SEDD_CHECK_ARG(graph == SEDD_ABSORB || graph == SEDD_UNIFORM, "predictor_step: unknown graph %d", graph);
+    SEDD_CHECK_ARG(step >= SEDD_STEP_EULER && step <= SEDD_STEP_DENOISE, "predictor_step: unknown step %d", step);
+    SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "predictor_step: unknown dtype %d", dtype);
+    SEDD_CHECK_ARG(M == 0 || (logscore && x && coef && u && xnew), "predictor_step: null pointer");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "predictor_step: bad sizes M=%ld L=%ld V=%d", (long)M,
+                   (long)L, V);
+    if (M == 0) return SEDD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEDD_F32) {
+        SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((predictor_step_kernel<float, G>),
+                                                  dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st, graph, step,
+                                                  (const float*)logscore, x, coef, u, xnew, M, L, V));
+    } else {
+        SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((predictor_step_kernel<bf16_t, G>),
+                                                  dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st, graph, step,
+                                                  (const bf16_t*)logscore, x, coef, u, xnew, M, L, V));
+    }
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ------------------------------------------------------------------------------ stand-alone Graph methods
+// mode 0: transp_rate (graph_lib.py:218-221 / :139-145)      mode 1: reverse_rate (:79-93)
+// mode 2: staggered_score (:264-269 / :162-165)              mode 3: transp_transition (:226-234 / :147-154)
+template <int G>
+__global__ void __launch_bounds__(TPB) graph_method_kernel(int graph, int mode, const int64_t* __restrict__ x,
+                                                           const float* __restrict__ score,
+                                                           const float* __restrict__ sig, float* __restrict__ out,
+                                                           int64_t M, int64_t L, int V) {
+    GroupIdx<G> g;
+    const int m = V - 1;
+    const float invV = 1.0f / (float)V;
+    for (int64_t row = g.first; row < M; row += g.stride) {
+        const int xi = x ? (int)x[row] : -1;
+        const float sg = sig ? sig[row / L] : 0.f;
+        const float* srow = score ? score + row * V : nullptr;
+        float* orow = out + row * V;
+        auto trate = [&](int j) -> float {
+            if (graph == SEDD_ABSORB) return (j == xi ? -1.f : 0.f) + (xi == m ? 1.f : 0.f);
+            return j == xi ? -((float)(V - 1)) / (float)V : invV;
+        };
+        if (mode == 0) {
+            for (int j = g.lane; j < V; j += G) orow[j] = trate(j);
+        } else if (mode == 1) {
+            float s = 0.f;
+            for (int j = g.lane; j < V; j += G) s += j == xi ? 0.f : trate(j) * srow[j];
+            s = group_sum<G>(s);
+            for (int j = g.lane; j < V; j += G) orow[j] = j == xi ? -s : trate(j) * srow[j];
+        } else if (mode == 2) {
+            float s = 0.f;
+            for (int j = g.lane; j < V; j += G) s += srow[j];
+            s = group_sum<G>(s);
+            if (graph == SEDD_ABSORB) {
+                const float e = expf(sg);
+                const float extra = (1.0f - e) * s;
+                for (int j = g.lane; j < V; j += G) {
+                    float v = srow[j] * e;
+                    if (j == m) v += extra;
+                    orow[j] = v;
+                }
+            } else {
+                const float w = expf(-sg);
+                const float a = (w - 1.0f) / ((float)V * w);
+                for (int j = g.lane; j < V; j += G) orow[j] = a * s + srow[j] / w;
+            }
+        } else {
+            const float en = expf(-sg);
+            const float om = 1.0f - en;
+            if (graph == SEDD_ABSORB) {
+                for (int j = g.lane; j < V; j += G)
+                    orow[j] = (j == xi ? en : 0.f) + (xi == m ? om : 0.f);
+            } else {
+                const float tval = (1.0f * om) / (float)V;
+                float ts = 0.f;
+                for (int j = g.lane; j < V; j += G) ts += j != xi ? tval : 0.f;
+                const float tdiag = 1.0f - group_sum<G>(ts);
+                for (int j = g.lane; j < V; j += G) orow[j] = j == xi ? tdiag : tval;
+            }
+        }
+    }
+}
+
+static int launch_graph_method(int graph, int mode, const int64_t* x, const float* score, const float* sig,
+                               float* out, int64_t M, int64_t L, int V, sedd_stream_t stream, const char* name) {
+    SEDD_CHECK_ARG(graph == SEDD_ABSORB || graph == SEDD_UNIFORM, "%s: unknown graph %d", name, graph);
+    SEDD_CHECK_ARG(M == 0 || out, "%s: out is null", name);
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "%s: bad sizes M=%ld L=%ld V=%d", name, (long)M, (long)L,
+                   V);
+    if (M == 0) return SEDD_OK;
+    SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((graph_method_kernel<G>), dim3(sedd_grid_for(M, TPB / G)), dim3(TPB),
+                                              0, (hipStream_t)stream, graph, mode, x, score, sig, out, M, L, V));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+extern "C" int sedd_transp_rate(int graph, const int64_t* x, float* out, int64_t M, int V, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M == 0 || (x), "transp_rate: x is null");
+    return launch_graph_method(graph, 0, x, nullptr, nullptr, out, M, 1, V, stream, "transp_rate");
+}
+extern "C" int sedd_reverse_rate(int graph, const int64_t* x, const float* score, float* out, int64_t M, int V,
+                                 sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M == 0 || (x && score), "reverse_rate: null pointer");
+    return launch_graph_method(graph, 1, x, score, nullptr, out, M, 1, V, stream, "reverse_rate");
+}
+extern "C" int sedd_staggered_score(int graph, const float* score, const float* dsigma, float* out, int64_t M,
+                                    int64_t L, int V, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M == 0 || (score && dsigma), "staggered_score: null pointer");
+    return launch_graph_method(graph, 2, nullptr, score, dsigma, out, M, L, V, stream, "staggered_score");
+}
+extern "C" int sedd_transp_transition(int graph, const int64_t* x, const float* sigma, float* out, int64_t M,
+                                      int64_t L, int V, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M == 0 || (x && sigma), "transp_transition: null pointer");
+    return launch_graph_method(graph, 3, x, nullptr, sigma, out, M, L, V, stream, "transp_transition");
+}
