@@ -131,10 +131,12 @@ int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const 
 int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L, int D,
                                   sedd_stream_t stream);
 
-/* Rotary (model/rotary.py:13-51): in-place NeoX rotation of the Q and K slots of qkv [B, L, 3, H, d];
- * conj != 0 applies the transposed rotation (backward).  cos/sin are computed in-kernel from
- * inv_freq_j = 1e4^(-2j/d) in fp32 (position = l). */
-int sedd_rotary_qkv(void* qkv, int dtype, int B, int L, int H, int d, int conj, sedd_stream_t stream);
+/* Rotary (model/rotary.py:13-51): in-place NeoX rotation of the Q and K slots of qkv [B, L, 3, H, d]:
+ * out = x*cos + rotate_half(x)*sin with rotate_half(x) = [-x2, x1]; conj != 0 applies the transposed rotation
+ * (backward).  cos/sin fp32 [L, d/2] are the first halves of the reference's cached tables (rotary.py:17-22;
+ * built once per L by the caller exactly like the reference builds them). d % 8 == 0. */
+int sedd_rotary_qkv(void* qkv, int dtype, const float* cos, const float* sin, int B, int L, int H, int d, int conj,
+                    sedd_stream_t stream);
 
 /* GELU(tanh) forward/backward (transformer.py:138): g = gelu(u); du = dg * gelu'(u). */
 int sedd_gelu_fwd(const void* u, void* g, int dtype, int64_t n, sedd_stream_t stream);

@@ -38,7 +38,7 @@ SIGNATURES = {
     "sedd_gate_residual_fwd": "ppipilpfpllip",
     "sedd_gate_residual_bwd": "ppipilpfppllip",
     "sedd_gate_residual_bwd_reduce": "ppl" + "llip",
-    "sedd_rotary_qkv": "piiiiiip",
+    "sedd_rotary_qkv": "pippiiiiip",
     "sedd_gelu_fwd": "ppilp",
     "sedd_gelu_bwd": "pppilp",
     "sedd_logits_epilogue": "pippillip",

@@ -1,0 +1,737 @@
+// HBM-bound model kernels: LayerNorm+adaLN modulate (fwd/bwd), gated residual with dropout (fwd/bwd), rotary,
+// GELU, SiLU, timestep embedding, embedding gather / scatter-add, logits epilogue, column sums, transpose, cast.
+// Reference call sites are cited per kernel (protlig_dd/model/*.py).  All are one-pass over their operands with
+// 16-byte (fp32) / 8-byte (bf16) per-lane vector accesses; row statistics are wave-level xor-shuffle reductions.
+#include "common.h"
+
+#define TPB 256
+#define CHUNK_ROWS 32  // rows per backward chunk (never straddles a batch element)
+
+// ---- 4-wide vector access helpers -------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4 o;
+    o.x = __uint_as_float(r.x << 16);
+    o.y = __uint_as_float(r.x & 0xffff0000u);
+    o.z = __uint_as_float(r.y << 16);
+    o.w = __uint_as_float(r.y & 0xffff0000u);
+    return o;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) {
+    union { bf16_t h[4]; uint2 u; } c;
+    c.h[0] = (bf16_t)v.x; c.h[1] = (bf16_t)v.y; c.h[2] = (bf16_t)v.z; c.h[3] = (bf16_t)v.w;
+    *reinterpret_cast<uint2*>(p) = c.u;
+}
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+
+#define DISPATCH_DT(code, TT, ...)                              \
+    do {                                                        \
+        if ((code) == SEDD_F32) { using TT = float; __VA_ARGS__; } \
+        else { using TT = bf16_t; __VA_ARGS__; }                \
+    } while (0)
+
+static bool dt_ok(int d) { return d == SEDD_F32 || d == SEDD_BF16; }
+
+// =================================================================================== LayerNorm + modulate fwd
+// transformer.py:30-38 + fused_add_dropout_scale.py:33-34.  One wave per row, row held in registers.
+template <typename TM, typename TO, int NV>
+__global__ void __launch_bounds__(TPB) ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const TM* __restrict__ shift,
+                                                         const TM* __restrict__ scale, int64_t mod_stride,
+                                                         TO* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int64_t M, int64_t L, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * D;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        v[k] = c < D ? load4<float>(xr + c) : f4(0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < D) {
+            const float a = v[k].x - mu, b = v[k].y - mu, cc = v[k].z - mu, d = v[k].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    const int64_t b = row / L;
+    TO* yr = y + row * D;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < D) {
+            const float4 ww = load4<float>(w + c);
+            float4 o;
+            o.x = (v[k].x - mu) * rs * ww.x; o.y = (v[k].y - mu) * rs * ww.y;
+            o.z = (v[k].z - mu) * rs * ww.z; o.w = (v[k].w - mu) * rs * ww.w;
+            if (scale) {
+                const float4 sc = load4<TM>(scale + b * mod_stride + c);
+                const float4 sh = load4<TM>(shift + b * mod_stride + c);
+                o.x = o.x * (1.0f + sc.x) + sh.x; o.y = o.y * (1.0f + sc.y) + sh.y;
+                o.z = o.z * (1.0f + sc.z) + sh.z; o.w = o.w * (1.0f + sc.w) + sh.w;
+            } else if (bias) {
+                const float4 bb = load4<float>(bias + c);
+                o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w;
+            }
+            store4<TO>(yr + c, o);
+        }
+    }
+}
+
+extern "C" int sedd_ln_modulate_fwd(const float* x, const float* w, const float* bias, const void* shift,
+                                    const void* scale, int mod_dtype, int64_t mod_stride, void* y, int out_dtype,
+                                    float* mean, float* rstd, int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(mod_dtype) && dt_ok(out_dtype), "ln_modulate_fwd: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "ln_modulate_fwd: bad sizes M=%ld L=%ld", (long)M, (long)L);
+    if (D <= 0 || D % 4 != 0 || D > 2048 || mod_stride % 4 != 0) {
+        sedd_set_error("ln_modulate_fwd: D=%d mod_stride=%ld unsupported (need D %% 4 == 0, D <= 2048)", D, (long)mod_stride);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(x && w && y, "ln_modulate_fwd: null pointer");
+    SEDD_CHECK_ARG((shift == nullptr) == (scale == nullptr), "ln_modulate_fwd: shift and scale go together");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(mod_dtype, TM, DISPATCH_DT(out_dtype, TO, {
+        if (D <= 1024)
+            hipLaunchKernelGGL((ln_mod_fwd_kernel<TM, TO, 4>), grid, dim3(TPB), 0, st, x, w, bias, (const TM*)shift,
+                               (const TM*)scale, mod_stride, (TO*)y, mean, rstd, M, L, D);
+        else
+            hipLaunchKernelGGL((ln_mod_fwd_kernel<TM, TO, 8>), grid, dim3(TPB), 0, st, x, w, bias, (const TM*)shift,
+                               (const TM*)scale, mod_stride, (TO*)y, mean, rstd, M, L, D);
+    }));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// =================================================================================== LayerNorm + modulate bwd
+// y = xhat*w*(1+sc)+sh, xhat = (x-mu)*rs.  g = dy*w*(1+sc);  dx = rs*(g - mean(g) - xhat*mean(g*xhat));
+// dw += dy*(1+sc)*xhat ; dsh += dy ; dsc += dy*xhat*w.  One block per chunk of <= 32 rows of one batch element.
+extern "C" int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L) {
+    if (L <= 0 || M <= 0) return 0;
+    return (M / L) * ((L + CHUNK_ROWS - 1) / CHUNK_ROWS);
+}
+
+template <typename TD, typename TM, int NV>
+__global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const TM* __restrict__ scale,
+                                                         int64_t mod_stride, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dx,
+                                                         int accumulate, float* __restrict__ ws, int64_t nchunk,
+                                                         int64_t L, int D) {
+    __shared__ float red[3 * NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t cpb = (L + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CHUNK_ROWS;
+    const int nrows = (int)((L - c0) < CHUNK_ROWS ? (L - c0) : CHUNK_ROWS);
+    float4 ww[NV], sc1[NV], aw[NV], ash[NV], asc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        ww[k] = c < D ? load4<float>(w + c) : f4(0.f);
+        float4 s = f4(0.f);
+        if (scale && c < D) s = load4<TM>(scale + b * mod_stride + c);
+        sc1[k] = make_float4(1.f + s.x, 1.f + s.y, 1.f + s.z, 1.f + s.w);
+        aw[k] = ash[k] = asc[k] = f4(0.f);
+    }
+    for (int r = wave; r < nrows; r += TPB / 64) {
+        const int64_t row = b * L + c0 + r;
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 256 + lane * 4;
+            float4 d = f4(0.f), xv = f4(mu);
+            if (c < D) { d = load4<TD>(dy + row * D + c); xv = load4<float>(x + row * D + c); }
+            xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            g[k] = make_float4(d.x * ww[k].x * sc1[k].x, d.y * ww[k].y * sc1[k].y, d.z * ww[k].z * sc1[k].z,
+                               d.w * ww[k].w * sc1[k].w);
+            s1 += (g[k].x + g[k].y) + (g[k].z + g[k].w);
+            s2 += (g[k].x * xh[k].x + g[k].y * xh[k].y) + (g[k].z * xh[k].z + g[k].w * xh[k].w);
+            aw[k].x += d.x * sc1[k].x * xh[k].x; aw[k].y += d.y * sc1[k].y * xh[k].y;
+            aw[k].z += d.z * sc1[k].z * xh[k].z; aw[k].w += d.w * sc1[k].w * xh[k].w;
+            ash[k].x += d.x; ash[k].y += d.y; ash[k].z += d.z; ash[k].w += d.w;
+            asc[k].x += d.x * xh[k].x * ww[k].x; asc[k].y += d.y * xh[k].y * ww[k].y;
+            asc[k].z += d.z * xh[k].z * ww[k].z; asc[k].w += d.w * xh[k].w * ww[k].w;
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 256 + lane * 4;
+            if (c < D) {
+                float4 o = make_float4(rs * (g[k].x - c1 - xh[k].x * c2), rs * (g[k].y - c1 - xh[k].y * c2),
+                                       rs * (g[k].z - c1 - xh[k].z * c2), rs * (g[k].w - c1 - xh[k].w * c2));
+                float* dp = dx + row * D + c;
+                if (accumulate) {
+                    const float4 p = load4<float>(dp);
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                store4<float>(dp, o);
+            }
+        }
+    }
+    // fold the 4 waves' column partials through LDS (wave by wave: deterministic order)
+    for (int wv = 0; wv < TPB / 64; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                float* r0 = red + (0 * NV + k) * 256 + lane * 4;
+                float* r1 = red + (1 * NV + k) * 256 + lane * 4;
+                float* r2 = red + (2 * NV + k) * 256 + lane * 4;
+                if (wv == 0) {
+                    store4<float>(r0, aw[k]); store4<float>(r1, ash[k]); store4<float>(r2, asc[k]);
+                } else {
+                    float4 p = load4<float>(r0);
+                    store4<float>(r0, make_float4(p.x + aw[k].x, p.y + aw[k].y, p.z + aw[k].z, p.w + aw[k].w));
+                    p = load4<float>(r1);
+                    store4<float>(r1, make_float4(p.x + ash[k].x, p.y + ash[k].y, p.z + ash[k].z, p.w + ash[k].w));
+                    p = load4<float>(r2);
+                    store4<float>(r2, make_float4(p.x + asc[k].x, p.y + asc[k].y, p.z + asc[k].z, p.w + asc[k].w));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 3 * NV * 64; i += TPB) {
+        const int plane = i / (NV * 64), rem = i % (NV * 64);
+        const int c = rem * 4;
+        if (c < D) store4<float>(ws + ((int64_t)plane * nchunk + chunk) * D + c, load4<float>(red + plane * NV * 256 + c));
+    }
+}
+
+extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                                    int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd,
+                                    float* dx, int accumulate, float* ws, int64_t M, int64_t L, int D,
+                                    sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dy_dtype) && dt_ok(mod_dtype), "ln_modulate_bwd: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "ln_modulate_bwd: bad sizes M=%ld L=%ld", (long)M, (long)L);
+    if (D <= 0 || D % 4 != 0 || D > 2048 || mod_stride % 4 != 0) {
+        sedd_set_error("ln_modulate_bwd: D=%d unsupported (need D %% 4 == 0, D <= 2048)", D);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(dy && x && w && mean && rstd && dx && ws, "ln_modulate_bwd: null pointer");
+    const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(dy_dtype, TD, DISPATCH_DT(mod_dtype, TM, {
+        if (D <= 1024)
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 4>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, accumulate, ws, nchunk, L, D);
+        else
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 8>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, accumulate, ws, nchunk, L, D);
+    }));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// out_k[b, j] = sum over the chunks of batch b of plane k;  plane 0 additionally summed over b into dw (atomic +=)
+__global__ void __launch_bounds__(TPB) chunk_reduce_kernel(const float* __restrict__ ws, int nplanes,
+                                                           float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ o2, int64_t ostride, int atomic0,
+                                                           int64_t nchunk, int64_t cpb, int D) {
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (j >= D) return;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int64_t c = 0; c < cpb; ++c)
+        for (int k = 0; k < nplanes; ++k) s[k] += ws[((int64_t)k * nchunk + b * cpb + c) * D + j];
+    float* outs[3] = {o0, o1, o2};
+    for (int k = 0; k < nplanes; ++k) {
+        if (!outs[k]) continue;
+        if (k == 0 && atomic0) atomicAdd(outs[0] + j, s[0]);
+        else outs[k][b * ostride + j] = s[k];
+    }
+}
+
+extern "C" int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float* dscale,
+                                           int64_t dmod_stride, int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0 && D > 0, "ln_modulate_bwd_reduce: bad sizes");
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(ws, "ln_modulate_bwd_reduce: ws is null");
+    const int64_t nchunk = sedd_ln_bwd_chunks(M, L), B = M / L;
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((D + TPB - 1) / TPB, (unsigned)B), dim3(TPB), 0, (hipStream_t)stream,
+                       ws, 3, dw, dshift, dscale, dmod_stride, 1, nchunk, nchunk / B, D);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ====================================================================================== gated residual fwd
+// fused_add_dropout_scale.py:13-48 with bias == None: out = residual + gate_b * dropout(a)
+template <typename TA, typename TM>
+__global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restrict__ res, const TA* __restrict__ a,
+                                                           const TM* __restrict__ gate, int64_t mod_stride,
+                                                           const uint8_t* __restrict__ keep, float inv_keep,
+                                                           float* __restrict__ out, int64_t M, int64_t L, int D) {
+    const int64_t nvec = M * (int64_t)(D / 4);
+    const int dv = D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * TPB) {
+        const int64_t row = i / dv;
+        const int c = (int)(i % dv) * 4;
+        const int64_t off = row * D + c;
+        float4 av = load4<TA>(a + off);
+        if (keep) {
+            const uchar4 k = *reinterpret_cast<const uchar4*>(keep + off);
+            av.x *= k.x ? inv_keep : 0.f; av.y *= k.y ? inv_keep : 0.f;
+            av.z *= k.z ? inv_keep : 0.f; av.w *= k.w ? inv_keep : 0.f;
+        }
+        const float4 g = load4<TM>(gate + (row / L) * mod_stride + c);
+        const float4 r = load4<float>(res + off);
+        store4<float>(out + off, make_float4(r.x + g.x * av.x, r.y + g.y * av.y, r.z + g.z * av.z, r.w + g.w * av.w));
+    }
+}
+
+extern "C" int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, const void* gate,
+                                      int mod_dtype, int64_t mod_stride, const uint8_t* keep, float inv_keep,
+                                      float* out, int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_fwd: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "gate_residual_fwd: bad sizes");
+    if (D <= 0 || D % 4 != 0 || mod_stride % 4 != 0) {
+        sedd_set_error("gate_residual_fwd: D=%d unsupported (need D %% 4 == 0)", D);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(residual && a && gate && out, "gate_residual_fwd: null pointer");
+    const dim3 grid(sedd_grid_for(M * (D / 4), TPB, 256 * 16));
+    DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
+        hipLaunchKernelGGL((gate_res_fwd_kernel<TA, TM>), grid, dim3(TPB), 0, (hipStream_t)stream, residual,
+                           (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, out, M, L, D)));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ====================================================================================== gated residual bwd
+// da = dout*gate*keep/(1-p);  dgate[b] = sum_l dout*a*keep/(1-p)  (chunk partials, folded by the reduce kernel)
+template <typename TA, typename TM>
+__global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restrict__ dout, const TA* __restrict__ a,
+                                                           const TM* __restrict__ gate, int64_t mod_stride,
+                                                           const uint8_t* __restrict__ keep, float inv_keep,
+                                                           TA* __restrict__ da, float* __restrict__ ws, int64_t L,
+                                                           int D) {
+    __shared__ float red[(TPB / 64) * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t cpb = (L + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CHUNK_ROWS;
+    const int nrows = (int)((L - c0) < CHUNK_ROWS ? (L - c0) : CHUNK_ROWS);
+    for (int cb = 0; cb < D; cb += 256) {  // 256-column slabs
+        const int c = cb + lane * 4;
+        float4 acc = f4(0.f);
+        if (c < D) {
+            const float4 g = load4<TM>(gate + b * mod_stride + c);
+            for (int r = wave; r < nrows; r += TPB / 64) {
+                const int64_t off = (b * L + c0 + r) * D + c;
+                const float4 d = load4<float>(dout + off);
+                float4 av = load4<TA>(a + off);
+                float4 kk = f4(1.f);
+                if (keep) {
+                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + off);
+                    kk = make_float4(k.x ? inv_keep : 0.f, k.y ? inv_keep : 0.f, k.z ? inv_keep : 0.f, k.w ? inv_keep : 0.f);
+                }
+                store4<TA>(da + off, make_float4(d.x * g.x * kk.x, d.y * g.y * kk.y, d.z * g.z * kk.z, d.w * g.w * kk.w));
+                acc.x += d.x * av.x * kk.x; acc.y += d.y * av.y * kk.y;
+                acc.z += d.z * av.z * kk.z; acc.w += d.w * av.w * kk.w;
+            }
+        }
+        store4<float>(red + wave * 256 + lane * 4, acc);
+        __syncthreads();
+        if (wave == 0 && c < D) {
+            float4 s = load4<float>(red + lane * 4);
+            for (int wv = 1; wv < TPB / 64; ++wv) {
+                const float4 p = load4<float>(red + wv * 256 + lane * 4);
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+            store4<float>(ws + chunk * D + c, s);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
+                                      int64_t mod_stride, const uint8_t* keep, float inv_keep, void* da, float* ws,
+                                      int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_bwd: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "gate_residual_bwd: bad sizes");
+    if (D <= 0 || D % 4 != 0 || mod_stride % 4 != 0) {
+        sedd_set_error("gate_residual_bwd: D=%d unsupported (need D %% 4 == 0)", D);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(dout && a && gate && da && ws, "gate_residual_bwd: null pointer");
+    const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
+    DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
+        hipLaunchKernelGGL((gate_res_bwd_kernel<TA, TM>), dim3((unsigned)nchunk), dim3(TPB), 0, (hipStream_t)stream,
+                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, (TA*)da, ws, L, D)));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+extern "C" int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L,
+                                             int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0 && D > 0, "gate_residual_bwd_reduce: bad sizes");
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(ws && dgate, "gate_residual_bwd_reduce: null pointer");
+    const int64_t nchunk = sedd_ln_bwd_chunks(M, L), B = M / L;
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((D + TPB - 1) / TPB, (unsigned)B), dim3(TPB), 0, (hipStream_t)stream,
+                       ws, 1, dgate, (float*)nullptr, (float*)nullptr, dmod_stride, 0, nchunk, nchunk / B, D);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ================================================================================================== rotary
+// rotary.py:30-39 on the Q and K slots of [B, L, 3, H, d]; one thread per 4 (first-half, second-half) pairs.
+template <typename T>
+__global__ void __launch_bounds__(TPB) rotary_kernel(T* __restrict__ qkv, const float* __restrict__ cs,
+                                                     const float* __restrict__ sn, int64_t M, int L, int H, int d,
+                                                     int conj) {
+    const int hv = d / 8;  // float4 groups per half
+    const int64_t total = M * 2 * H * hv;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+        const int j = (int)(i % hv) * 4;
+        int64_t t = i / hv;
+        const int h = (int)(t % H); t /= H;
+        const int slot = (int)(t % 2);
+        const int64_t row = t / 2;
+        const int l = (int)(row % L);
+        T* p = qkv + ((row * 3 + slot) * H + h) * d + j;
+        const float4 x1 = load4<T>(p), x2 = load4<T>(p + d / 2);
+        const float4 c = load4<float>(cs + (int64_t)l * (d / 2) + j);
+        float4 s = load4<float>(sn + (int64_t)l * (d / 2) + j);
+        if (conj) s = make_float4(-s.x, -s.y, -s.z, -s.w);
+        store4<T>(p, make_float4(x1.x * c.x - x2.x * s.x, x1.y * c.y - x2.y * s.y, x1.z * c.z - x2.z * s.z,
+                                 x1.w * c.w - x2.w * s.w));
+        store4<T>(p + d / 2, make_float4(x2.x * c.x + x1.x * s.x, x2.y * c.y + x1.y * s.y, x2.z * c.z + x1.z * s.z,
+                                         x2.w * c.w + x1.w * s.w));
+    }
+}
+
+extern "C" int sedd_rotary_qkv(void* qkv, int dtype, const float* cos, const float* sin, int B, int L, int H, int d,
+                               int conj, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "rotary_qkv: bad dtype");
+    SEDD_CHECK_ARG(B >= 0 && L > 0 && H > 0, "rotary_qkv: bad sizes");
+    if (d <= 0 || d % 8 != 0) {
+        sedd_set_error("rotary_qkv: head dim %d unsupported (need d %% 8 == 0)", d);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (B == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(qkv && cos && sin, "rotary_qkv: null pointer");
+    const int64_t M = (int64_t)B * L;
+    const dim3 grid(sedd_grid_for(M * 2 * H * (d / 8), TPB, 256 * 16));
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((rotary_kernel<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (T*)qkv, cos,
+                                             sin, M, L, H, d, conj));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// =========================================================================================== GELU / SiLU
+__device__ __forceinline__ float gelu_tanh(float u) {
+    const float t = tanhf(0.7978845608028654f * (u + 0.044715f * u * u * u));
+    return 0.5f * u * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float u) {
+    const float t = tanhf(0.7978845608028654f * (u + 0.044715f * u * u * u));
+    return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * u * u);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// mode 0: gelu fwd (b unused) 1: gelu bwd (a=u, b=dg) 2: silu fwd 3: silu bwd (a=x, b=dy)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(TPB) act_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o,
+                                                  int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        const float4 x = load4<T>(a + i * 4);
+        float4 y = f4(0.f);
+        if (MODE == 1 || MODE == 3) y = load4<T>(b + i * 4);
+        float4 r;
+        if (MODE == 0) r = make_float4(gelu_tanh(x.x), gelu_tanh(x.y), gelu_tanh(x.z), gelu_tanh(x.w));
+        else if (MODE == 1) r = make_float4(y.x * gelu_tanh_grad(x.x), y.y * gelu_tanh_grad(x.y), y.z * gelu_tanh_grad(x.z), y.w * gelu_tanh_grad(x.w));
+        else if (MODE == 2) r = make_float4(silu(x.x), silu(x.y), silu(x.z), silu(x.w));
+        else r = make_float4(y.x * silu_grad(x.x), y.y * silu_grad(x.y), y.z * silu_grad(x.z), y.w * silu_grad(x.w));
+        store4<T>(o + i * 4, r);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+        const int64_t i = nv * 4 + threadIdx.x;
+        const float x = to_f32<T>(a[i]);
+        const float y = (MODE == 1 || MODE == 3) ? to_f32<T>(b[i]) : 0.f;
+        float r;
+        if (MODE == 0) r = gelu_tanh(x);
+        else if (MODE == 1) r = y * gelu_tanh_grad(x);
+        else if (MODE == 2) r = silu(x);
+        else r = y * silu_grad(x);
+        o[i] = from_f32<T>(r);
+    }
+}
+
+template <int MODE>
+static int launch_act(const void* a, const void* b, void* o, int dtype, int64_t n, sedd_stream_t stream, const char* nm) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "%s: bad dtype", nm);
+    SEDD_CHECK_ARG(n >= 0, "%s: bad size", nm);
+    if (n == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(a && o && (MODE == 0 || MODE == 2 || b), "%s: null pointer", nm);
+    const dim3 grid(sedd_grid_for(n / 4 + 1, TPB, 256 * 16));
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((act_kernel<T, MODE>), grid, dim3(TPB), 0, (hipStream_t)stream,
+                                             (const T*)a, (const T*)b, (T*)o, n));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+extern "C" int sedd_gelu_fwd(const void* u, void* g, int dtype, int64_t n, sedd_stream_t stream) {
+    return launch_act<0>(u, nullptr, g, dtype, n, stream, "gelu_fwd");
+}
+extern "C" int sedd_gelu_bwd(const void* u, const void* dg, void* du, int dtype, int64_t n, sedd_stream_t stream) {
+    return launch_act<1>(u, dg, du, dtype, n, stream, "gelu_bwd");
+}
+extern "C" int sedd_silu_fwd(const float* x, float* y, int64_t n, sedd_stream_t stream) {
+    return launch_act<2>(x, nullptr, y, SEDD_F32, n, stream, "silu_fwd");
+}
+extern "C" int sedd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, sedd_stream_t stream) {
+    return launch_act<3>(x, dy, dx, SEDD_F32, n, stream, "silu_bwd");
+}
+
+// ======================================================================================= timestep embedding
+// transformer.py:70-89
+__global__ void __launch_bounds__(TPB) timestep_embedding_kernel(const float* __restrict__ sigma,
+                                                                 float* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < B * half; i += gridDim.x * TPB) {
+        const int b = i / half, k = i % half;
+        const float f = expf((-9.210340371976184f * (float)k) / (float)half);
+        const float arg = sigma[b] * f;
+        out[(int64_t)b * dim + k] = cosf(arg);
+        out[(int64_t)b * dim + half + k] = sinf(arg);
+    }
+}
+extern "C" int sedd_timestep_embedding(const float* sigma, float* out, int B, int dim, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(B >= 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad sizes B=%d dim=%d", B, dim);
+    if (B == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(sigma && out, "timestep_embedding: null pointer");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(sedd_grid_for((int64_t)B * dim / 2, TPB)), dim3(TPB), 0,
+                       (hipStream_t)stream, sigma, out, B, dim);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ================================================================================================ embedding
+// transformer.py:193-218
+__global__ void __launch_bounds__(TPB) embedding_fwd_kernel(const float* __restrict__ table,
+                                                            const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                            int64_t M, int D) {
+    const int dv = D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M * dv; i += (int64_t)gridDim.x * TPB) {
+        const int64_t row = i / dv;
+        const int c = (int)(i % dv) * 4;
+        store4<float>(out + row * D + c, load4<float>(table + idx[row] * D + c));
+    }
+}
+extern "C" int sedd_embedding_fwd(const float* table, const int64_t* idx, float* out, int64_t M, int D, int V,
+                                  sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && D > 0 && V > 0, "embedding_fwd: bad sizes");
+    if (D % 4 != 0) { sedd_set_error("embedding_fwd: D=%d unsupported (need D %% 4 == 0)", D); return SEDD_ERR_UNSUPPORTED_SHAPE; }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(table && idx && out, "embedding_fwd: null pointer");
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(sedd_grid_for(M * (D / 4), TPB, 256 * 16)), dim3(TPB), 0,
+                       (hipStream_t)stream, table, idx, out, M, D);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// scatter-add.  Small vocab (<= 64 rows): a block reduces 512 rows x 64 columns into LDS first, so the global
+// float atomics drop from M*D to (M/512)*V*D; large vocab: direct global atomics (little contention).
+#define EMB_ROWS 512
+__global__ void __launch_bounds__(TPB) embedding_bwd_small_kernel(const float* __restrict__ dout,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  float* __restrict__ dtable, int64_t M, int D, int V) {
+    __shared__ float acc[64 * 64];
+    const int col = threadIdx.x & 63, rr = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const int64_t r0 = (int64_t)blockIdx.y * EMB_ROWS;
+    for (int i = threadIdx.x; i < V * 64; i += TPB) acc[i] = 0.f;
+    __syncthreads();
+    if (c < D)
+        for (int r = rr; r < EMB_ROWS && r0 + r < M; r += TPB / 64)
+            atomicAdd(&acc[(int)idx[r0 + r] * 64 + col], dout[(r0 + r) * D + c]);
+    __syncthreads();
+    if (c < D)
+        for (int v = rr; v < V; v += TPB / 64) {
+            const float s = acc[v * 64 + col];
+            if (s != 0.f) atomicAdd(dtable + (int64_t)v * D + c, s);
+        }
+}
+__global__ void __launch_bounds__(TPB) embedding_bwd_large_kernel(const float* __restrict__ dout,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  float* __restrict__ dtable, int64_t M, int D) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M * D; i += (int64_t)gridDim.x * TPB) {
+        const int64_t row = i / D;
+        atomicAdd(dtable + idx[row] * D + (i % D), dout[i]);
+    }
+}
+extern "C" int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t M, int D, int V,
+                                  sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && D > 0 && V > 0, "embedding_bwd: bad sizes");
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(dout && idx && dtable, "embedding_bwd: null pointer");
+    if (V <= 64)
+        hipLaunchKernelGGL(embedding_bwd_small_kernel, dim3((D + 63) / 64, (unsigned)((M + EMB_ROWS - 1) / EMB_ROWS)),
+                           dim3(TPB), 0, (hipStream_t)stream, dout, idx, dtable, M, D, V);
+    else
+        hipLaunchKernelGGL(embedding_bwd_large_kernel, dim3(sedd_grid_for(M * D, TPB, 256 * 16)), dim3(TPB), 0,
+                           (hipStream_t)stream, dout, idx, dtable, M, D);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ========================================================================================= logits epilogue
+// transformer.py:313-322
+template <typename T>
+__global__ void __launch_bounds__(TPB) logits_epilogue_kernel(T* __restrict__ x, const float* __restrict__ sigma,
+                                                              const int64_t* __restrict__ idx, int scale_by_sigma,
+                                                              int64_t M, int64_t L, int V) {
+    const float lv = logf((float)(V - 1));
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M * V; i += (int64_t)gridDim.x * TPB) {
+        const int64_t row = i / V;
+        const int j = (int)(i % V);
+        float v = to_f32<T>(x[i]);
+        if (scale_by_sigma) {
+            const float el = to_f32<T>(from_f32<T>(logf(esigm1f(sigma[row / L]))));  // .log().to(x.dtype)
+            v = to_f32<T>(from_f32<T>(v - el));
+            v = v - lv;
+        }
+        if (j == idx[row]) v = 0.f;
+        x[i] = from_f32<T>(v);
+    }
+}
+extern "C" int sedd_logits_epilogue(void* logits, int dtype, const float* sigma, const int64_t* idx,
+                                    int scale_by_sigma, int64_t M, int64_t L, int V, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "logits_epilogue: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "logits_epilogue: bad sizes");
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(logits && idx && (!scale_by_sigma || sigma), "logits_epilogue: null pointer");
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((logits_epilogue_kernel<T>), dim3(sedd_grid_for(M * V, TPB, 256 * 16)),
+                                             dim3(TPB), 0, (hipStream_t)stream, (T*)logits, sigma, idx,
+                                             scale_by_sigma, M, L, V));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+template <typename T>
+__global__ void __launch_bounds__(TPB) logits_epilogue_bwd_kernel(T* __restrict__ dl, const int64_t* __restrict__ idx,
+                                                                  int64_t M, int V) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < M; r += (int64_t)gridDim.x * TPB) {
+        const int64_t j = idx[r];
+        if (j >= 0 && j < V) dl[r * V + j] = from_f32<T>(0.f);
+    }
+}
+extern "C" int sedd_logits_epilogue_bwd(void* dlogits, int dtype, const int64_t* idx, int64_t M, int V,
+                                        sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "logits_epilogue_bwd: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && V > 0, "logits_epilogue_bwd: bad sizes");
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(dlogits && idx, "logits_epilogue_bwd: null pointer");
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((logits_epilogue_bwd_kernel<T>), dim3(sedd_grid_for(M, TPB)), dim3(TPB),
+                                             0, (hipStream_t)stream, (T*)dlogits, idx, M, V));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ================================================================================================== colsum
+#define CS_ROWS 128
+template <typename T>
+__global__ void __launch_bounds__(TPB) colsum_kernel(const T* __restrict__ a, int64_t lda, float* __restrict__ out,
+                                                     int64_t M, int N) {
+    __shared__ float red[(TPB / 64) * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    float s = 0.f;
+    if (c < N)
+        for (int r = wave; r < CS_ROWS && r0 + r < M; r += TPB / 64) s += to_f32<T>(a[(r0 + r) * lda + c]);
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < N) {
+        for (int wv = 1; wv < TPB / 64; ++wv) s += red[wv * 64 + lane];
+        atomicAdd(out + c, s);
+    }
+}
+extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, int accumulate, int64_t M, int N,
+                           sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "colsum: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && N > 0 && lda >= N, "colsum: bad sizes");
+    SEDD_CHECK_ARG(out, "colsum: out is null");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { sedd_set_error("colsum: memset failed"); return SEDD_ERR_LAUNCH; }
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(a, "colsum: a is null");
+    const dim3 grid((N + 63) / 64, (unsigned)((M + CS_ROWS - 1) / CS_ROWS));
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(TPB), 0, st, (const T*)a, lda, out, M, N));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// =============================================================================================== transpose
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(TPB) transpose_kernel(const TI* __restrict__ a, int64_t lda, TO* __restrict__ o,
+                                                        int64_t ldo, int64_t M, int64_t N) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    for (int r = ty; r < 64; r += TPB / 64)
+        if (m0 + r < M && n0 + tx < N) tile[r][tx] = to_f32<TI>(a[(m0 + r) * lda + n0 + tx]);
+    __syncthreads();
+    for (int r = ty; r < 64; r += TPB / 64)
+        if (n0 + r < N && m0 + tx < M) o[(n0 + r) * ldo + m0 + tx] = from_f32<TO>(tile[tx][r]);
+}
+extern "C" int sedd_transpose(const void* a, int a_dtype, int64_t lda, void* out, int out_dtype, int64_t ldo,
+                              int64_t M, int64_t N, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(out_dtype), "transpose: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && N >= 0 && lda >= N && ldo >= M, "transpose: bad sizes");
+    if (M == 0 || N == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(a && out, "transpose: null pointer");
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    DISPATCH_DT(a_dtype, TI, DISPATCH_DT(out_dtype, TO,
+        hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(TPB), 0, (hipStream_t)stream, (const TI*)a, lda,
+                           (TO*)out, ldo, M, N)));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ==================================================================================================== cast
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(TPB) cast_kernel(const TI* __restrict__ a, TO* __restrict__ o, int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB)
+        store4<TO>(o + i * 4, load4<TI>(a + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) o[nv * 4 + threadIdx.x] = from_f32<TO>(to_f32<TI>(a[nv * 4 + threadIdx.x]));
+}
+extern "C" int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(in_dtype) && dt_ok(out_dtype), "cast: bad dtype");
+    SEDD_CHECK_ARG(n >= 0, "cast: bad size");
+    if (n == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(in && out, "cast: null pointer");
+    const dim3 grid(sedd_grid_for(n / 4 + 1, TPB, 256 * 16));
+    DISPATCH_DT(in_dtype, TI, DISPATCH_DT(out_dtype, TO,
+        hipLaunchKernelGGL((cast_kernel<TI, TO>), grid, dim3(TPB), 0, (hipStream_t)stream, (const TI*)in, (TO*)out, n)));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}

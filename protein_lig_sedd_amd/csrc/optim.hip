@@ -1,0 +1,112 @@
+// Optimiser pass over the flat fp32 parameter buffer: clip -> AdamW -> EMA -> bf16 compute copy, and the
+// deterministic gradient-norm reduction that feeds the clip coefficient.
+// Reference: protlig_dd/processing/losses.py:35-69 (AdamW, warm-up, clip_grad_norm_), protlig_dd/model/ema.py:32-52.
+// HBM-bound: reads p,g,m,v,ema (20 B/param), writes p,m,v,ema (+2 B bf16 copy).
+#include "common.h"
+
+#define TPB 256
+
+__global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        float* __restrict__ ema, bf16_t* __restrict__ pb,
+                                                        const float* __restrict__ clip, float gscale, float decay_mul,
+                                                        float beta1, float beta2, float eps, float step_size,
+                                                        float inv_bc2_sqrt, float one_m_ema, int64_t n) {
+    const float cs = (clip ? clip[0] : 1.0f) * gscale;
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* Mm = &mm.x; float* Vv = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = G[k] * cs;
+            P[k] *= decay_mul;
+            Mm[k] = Mm[k] * beta1 + gk * (1.0f - beta1);
+            Vv[k] = Vv[k] * beta2 + gk * gk * (1.0f - beta2);
+            const float denom = sqrtf(Vv[k]) * inv_bc2_sqrt + eps;
+            P[k] -= step_size * (Mm[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (ema) {
+            float4 ee = reinterpret_cast<float4*>(ema)[i];
+            ee.x -= one_m_ema * (ee.x - pp.x); ee.y -= one_m_ema * (ee.y - pp.y);
+            ee.z -= one_m_ema * (ee.z - pp.z); ee.w -= one_m_ema * (ee.w - pp.w);
+            reinterpret_cast<float4*>(ema)[i] = ee;
+        }
+        if (pb) {
+            union { bf16_t h[4]; uint2 u; } c;
+            c.h[0] = (bf16_t)pp.x; c.h[1] = (bf16_t)pp.y; c.h[2] = (bf16_t)pp.z; c.h[3] = (bf16_t)pp.w;
+            reinterpret_cast<uint2*>(pb)[i] = c.u;
+        }
+    }
+}
+
+extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                                   const float* clip_coef, float grad_scale, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, int step, float ema_decay, int64_t n,
+                                   sedd_stream_t stream) {
+    SEDD_CHECK_ARG(n >= 0 && step >= 1, "adamw_ema_step: bad n=%ld step=%d", (long)n, step);
+    if (n % 4 != 0) {
+        sedd_set_error("adamw_ema_step: n=%ld must be a multiple of 4 (pad the flat buffer)", (long)n);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (n == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(p && g && m && v, "adamw_ema_step: null pointer");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(sedd_grid_for(n / 4, TPB, 256 * 16)), dim3(TPB), 0, (hipStream_t)stream,
+                       p, g, m, v, ema, (bf16_t*)p_bf16, clip_coef, grad_scale, decay_mul, beta1, beta2, eps, step_size,
+                       inv_bc2_sqrt, 1.0f - ema_decay, n);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ---- sum of squares, two deterministic stages ---------------------------------------------------------------
+#define SUMSQ_MAX_BLOCKS 1024
+__global__ void __launch_bounds__(TPB) sumsq_stage1(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
+    __shared__ float red[TPB / 64];
+    float s = 0.f;
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        const float4 x = reinterpret_cast<const float4*>(g)[i];
+        s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float x = g[nv * 4 + threadIdx.x]; s += x * x; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(TPB) sumsq_stage2(const float* __restrict__ ws, int nb, float gscale, float max_norm,
+                                                    float* __restrict__ out) {
+    __shared__ float red[TPB / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += TPB) s += ws[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        out[0] = t;
+        if (max_norm > 0.f) out[1] = fminf(1.0f, max_norm / (sqrtf(t) * gscale + 1e-6f));
+    }
+}
+
+extern "C" int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float max_norm, float* ws, float* out,
+                               sedd_stream_t stream) {
+    SEDD_CHECK_ARG(n >= 0, "sumsq_clip: bad n");
+    SEDD_CHECK_ARG(ws && out && (n == 0 || g), "sumsq_clip: null pointer");
+    const int nb = n == 0 ? 1 : sedd_grid_for(n / 4 + 1, TPB * 4, SUMSQ_MAX_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_stage1, dim3(nb), dim3(TPB), 0, st, g, n, ws);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TPB), 0, st, ws, nb, gscale, max_norm, out);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
