@@ -1,0 +1,497 @@
+// Softmax attention forward / backward on MFMA tiles — the flash-attn boundary of the reference
+// (model/transformer.py:172-183, flash_attn_varlen_qkvpacked_func: non-causal, no dropout, scale d^-1/2) and the
+// core of nn.MultiheadAttention (transformers_protlig_cross.py:135-138, :305), as one strided kernel family
+// (Lq != Lk and a key mask allowed).  Written for 64-lane waves from the start:
+//
+//  * every product is computed TRANSPOSED (S^T = K Q^T, O^T = V^T P^T, dQ^T = K^T dS^T, ...) with
+//    v_mfma_f32_16x16x32_bf16, so the softmax axis of a query lives in the registers of ONE lane column
+//    (C/D map: col = lane & 15 = query, row = 4*(lane >> 4) + reg = key): row max / row sum are 16 local ops plus
+//    two xor-shuffles, the running max / sum / LSE / delta of a query are lane-local scalars, and the fp32
+//    probability tile is re-used in place as the next MFMA's B operand (accumulator-as-operand, no LDS round trip);
+//  * the operand that must be read "column-wise" (V for O^T, K for dQ^T, dO/Q for dV^T/dK^T) is read from the same
+//    row-major LDS tile with ds_read_b64_tr_b16 (hardware transposed read), so each K/V/Q/dO tile is staged once;
+//  * K/V tiles are staged through LDS in 16-byte chunks with a 16-byte row pad (conflict-free ds_read_b128).
+//
+// The fp32 instantiation (exact v_mfma_f32_16x16x4_f32) exists for the fp32 parity configuration and the
+// fp32-autocast cross model.  Backward is two deterministic kernels (dQ per query block, dK/dV per key block; no
+// atomics); delta = rowsum(dO * O) comes from a small pre-pass.
+// MFMA-bound: forward 4*B*H*Lq*Lk*d flop, backward 14*B*H*Lq*Lk*d (7 products incl. the recomputed S and dP).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define TILE 64          // rows of a staged LDS tile (keys in fwd / dQ, queries in dK/dV)
+#define OWN_PER_WAVE 32  // rows owned by a wave (2 MFMA tiles)
+#define OWN_PER_BLOCK 128
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+template <typename T> struct Op;
+template <> struct Op<bf16_t> { using type = bf16x8; static constexpr int KS = 32; static constexpr int PAD = 8; };
+template <> struct Op<float> { using type = float; static constexpr int KS = 4; static constexpr int PAD = 4; };
+
+template <typename T, int D> struct RowFrag { typename Op<T>::type v[D / Op<T>::KS]; };
+
+// fragment of the tile row this lane owns (row = lane & 15 of the tile), g = lane >> 4
+template <typename T, int D> __device__ __forceinline__ RowFrag<T, D> load_rowfrag(const T* row, int g) {
+    RowFrag<T, D> f;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int s = 0; s < D / 32; ++s) f.v[s] = *reinterpret_cast<const bf16x8*>(row + 32 * s + 8 * g);
+    } else {
+#pragma unroll
+        for (int s = 0; s < D / 4; ++s) f.v[s] = row[4 * s + g];
+    }
+    return f;
+}
+template <typename T, int D> __device__ __forceinline__ RowFrag<T, D> zero_rowfrag() {
+    RowFrag<T, D> f;
+#pragma unroll
+    for (int s = 0; s < D / Op<T>::KS; ++s) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f.v[s][j] = (__bf16)0.f;
+        } else f.v[s] = 0.f;
+    }
+    return f;
+}
+
+// acc[16x16] += A_rows x B_rows^T over the head dim (C/D: col = B's row (lane & 15), row = A's row 4g + reg)
+template <typename T, int D>
+__device__ __forceinline__ f32x4 mma_rows(const RowFrag<T, D>& a, const RowFrag<T, D>& b, f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < D / Op<T>::KS; ++s) {
+        if constexpr (sizeof(T) == 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[s], b.v[s], acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[s], b.v[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// accT[dt] (16 dims x 16 own rows) += X^T x W over the 64 rows of the LDS tile X[64][LS]; W[t][r] is this lane's
+// fp32 weight for tile row 16t + 4g + r and its own column (lane & 15).  bf16: rows are consumed 32 at a time in the
+// permuted order (4g+j of tile 2s, then 16+4g+j of tile 2s+1) on BOTH operands, which a sum over rows allows.
+template <typename T, int D>
+__device__ __forceinline__ void mma_tr(f32x4 (&accT)[D / 16], const T* X, const f32x4 (&W)[4], int lane) {
+    constexpr int LS = D + Op<T>::PAD;
+    const int g = lane >> 4, i = lane & 15;
+    if constexpr (sizeof(T) == 2) {
+        const int q = i >> 2, p = i & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[j] = (__bf16)W[2 * s][j]; b[4 + j] = (__bf16)W[2 * s + 1][j]; }
+            const T* r0 = X + (32 * s + 4 * g + q) * LS + 4 * p;
+            const T* r1 = r0 + 16 * LS;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + dt * 16));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r1 + dt * 16));
+                union { struct { s16x4 lo, hi; } s; bf16x8 v; } a;
+                a.s.lo = lo; a.s.hi = hi;
+                accT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b, accT[dt], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T* row = X + (16 * t + 4 * g + r) * LS + i;
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt)
+                    accT[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[dt * 16], W[t][r], accT[dt], 0, 0, 0);
+            }
+    }
+}
+
+// stage rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks
+template <typename T, int D>
+__device__ __forceinline__ void stage_tile(T* lds, const T* g, int64_t ls, int r0, int nrows) {
+    constexpr int LS = D + Op<T>::PAD;
+    constexpr int EPC = 16 / sizeof(T);  // elements per chunk
+    constexpr int CPR = D / EPC;
+    for (int c = threadIdx.x; c < TILE * CPR; c += blockDim.x) {
+        const int row = c / CPR, cc = c % CPR;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (r0 + row < nrows) val = *reinterpret_cast<const uint4*>(g + (int64_t)(r0 + row) * ls + cc * EPC);
+        *reinterpret_cast<uint4*>(lds + row * LS + cc * EPC) = val;
+    }
+}
+
+template <typename T> __device__ __forceinline__ void store4T(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4T<float>(float* p, f32x4 v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4T<bf16_t>(bf16_t* p, f32x4 v) {
+    union { bf16_t h[4]; uint2 u; } c;
+    c.h[0] = (bf16_t)v[0]; c.h[1] = (bf16_t)v[1]; c.h[2] = (bf16_t)v[2]; c.h[3] = (bf16_t)v[3];
+    *reinterpret_cast<uint2*>(p) = c.u;
+}
+
+struct AttnShape {
+    int H, Lq, Lk;
+    int64_t q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls;
+    float scale;
+};
+
+// ==================================================================================================== forward
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v, T* __restrict__ o,
+                                                       float* __restrict__ lse, const uint8_t* __restrict__ mask,
+                                                       AttnShape sh) {
+    constexpr int LS = D + Op<T>::PAD;
+    __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
+    __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
+    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
+    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
+    const uint8_t* mb = mask ? mask + (int64_t)b * sh.Lk : nullptr;
+    const float sl2 = sh.scale * LOG2E;
+
+    RowFrag<T, D> qf[2];
+    int qrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        qrow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        qf[mt] = qrow[mt] < sh.Lq ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
+    }
+    float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    f32x4 acc[2][D / 16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < sh.Lk; k0 += TILE) {
+        __syncthreads();
+        stage_tile<T, D>(Ks, kb, sh.kv_ls, k0, sh.Lk);
+        stage_tile<T, D>(Vs, vb, sh.kv_ls, k0, sh.Lk);
+        __syncthreads();
+        f32x4 S[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const RowFrag<T, D> kf = load_rowfrag<T, D>(Ks + (16 * t + i) * LS, g);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) S[mt][t] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+        bool valid[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * t + 4 * g + r;
+                valid[t][r] = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[mt][t][r] = valid[t][r] ? S[mt][t][r] * sl2 : -INFINITY;
+                    mx = fmaxf(mx, S[mt][t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[mt], mx);
+            const float ms = mn == -INFINITY ? 0.f : mn;  // fully masked so far: keep everything at 0
+            const float alpha = exp2f(m[mt] - ms);
+            m[mt] = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(S[mt][t][r] - ms);
+                    S[mt][t][r] = p;
+                    rs += p;
+                }
+            lsum[mt] = lsum[mt] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] *= alpha;
+            mma_tr<T, D>(acc[mt], Vs, S[mt], lane);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float l = lsum[mt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qrow[mt] < sh.Lq) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            T* orow = o + b * sh.o_bs + (int64_t)qrow[mt] * sh.o_ls + (int64_t)h * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(orow + dt * 16 + 4 * g, acc[mt][dt] * inv);
+            if (g == 0) lse[((int64_t)b * sh.H + h) * sh.Lq + qrow[mt]] = (m[mt] + log2f(l)) * LN2;
+        }
+    }
+}
+
+// ============================================================================================ delta pre-pass
+template <typename T>
+__global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int H, int Lq, int D,
+                                                         int64_t o_bs, int64_t o_ls) {
+    const int64_t total = (int64_t)B * H * Lq;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int qi = (int)(idx % Lq);
+        const int h = (int)((idx / Lq) % H);
+        const int b = (int)(idx / ((int64_t)Lq * H));
+        const int64_t off = b * o_bs + (int64_t)qi * o_ls + (int64_t)h * D;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += to_f32<T>(o[off + d]) * to_f32<T>(dout[off + d]);
+        delta[idx] = s;
+    }
+}
+
+// ================================================================================================ dQ kernel
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                          const T* __restrict__ v, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta,
+                                                          const uint8_t* __restrict__ mask, T* __restrict__ dq,
+                                                          AttnShape sh) {
+    constexpr int LS = D + Op<T>::PAD;
+    __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
+    __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
+    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
+    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
+    const T* dob = dout + b * sh.o_bs + (int64_t)h * D;
+    const uint8_t* mb = mask ? mask + (int64_t)b * sh.Lk : nullptr;
+    const float sl2 = sh.scale * LOG2E;
+
+    RowFrag<T, D> qf[2], dof[2];
+    int qrow[2];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        qrow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        const bool ok = qrow[mt] < sh.Lq;
+        qf[mt] = ok ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
+        dof[mt] = ok ? load_rowfrag<T, D>(dob + (int64_t)qrow[mt] * sh.o_ls, g) : zero_rowfrag<T, D>();
+        const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (ok ? qrow[mt] : 0);
+        lq[mt] = ok ? lse[si] * LOG2E : 0.f;
+        dl[mt] = ok ? delta[si] : 0.f;
+    }
+    f32x4 acc[2][D / 16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < sh.Lk; k0 += TILE) {
+        __syncthreads();
+        stage_tile<T, D>(Ks, kb, sh.kv_ls, k0, sh.Lk);
+        stage_tile<T, D>(Vs, vb, sh.kv_ls, k0, sh.Lk);
+        __syncthreads();
+        f32x4 S[2][4], dP[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const RowFrag<T, D> kf = load_rowfrag<T, D>(Ks + (16 * t + i) * LS, g);
+            const RowFrag<T, D> vf = load_rowfrag<T, D>(Vs + (16 * t + i) * LS, g);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                S[mt][t] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                dP[mt][t] = mma_rows<T, D>(vf, dof[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * t + 4 * g + r;
+                const bool valid = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float p = valid ? exp2f(S[mt][t][r] * sl2 - lq[mt]) : 0.f;
+                    S[mt][t][r] = p * (dP[mt][t][r] - dl[mt]) * sh.scale;  // dS^T
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) mma_tr<T, D>(acc[mt], Ks, S[mt], lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+        if (qrow[mt] < sh.Lq) {
+            T* row = dq + b * sh.q_bs + (int64_t)qrow[mt] * sh.q_ls + (int64_t)h * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(row + dt * 16 + 4 * g, acc[mt][dt]);
+        }
+}
+
+// ============================================================================================ dK / dV kernel
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                           const T* __restrict__ v, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta,
+                                                           const uint8_t* __restrict__ mask, T* __restrict__ dk,
+                                                           T* __restrict__ dv, AttnShape sh) {
+    constexpr int LS = D + Op<T>::PAD;
+    __shared__ __attribute__((aligned(16))) T Qs[TILE * LS];
+    __shared__ __attribute__((aligned(16))) T dOs[TILE * LS];
+    __shared__ float lse_s[TILE], del_s[TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
+    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
+    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
+    const T* dob = dout + b * sh.o_bs + (int64_t)h * D;
+    const float sl2 = sh.scale * LOG2E;
+
+    RowFrag<T, D> kf[2], vf[2];
+    int krow[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        krow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        const bool ok = krow[mt] < sh.Lk;
+        kf[mt] = ok ? load_rowfrag<T, D>(kb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
+        vf[mt] = ok ? load_rowfrag<T, D>(vb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
+        kvalid[mt] = ok && (!mask || mask[(int64_t)b * sh.Lk + krow[mt]]);
+    }
+    f32x4 adk[2][D / 16], adv[2][D / 16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) adk[mt][dt] = adv[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < sh.Lq; q0 += TILE) {
+        __syncthreads();
+        stage_tile<T, D>(Qs, qb, sh.q_ls, q0, sh.Lq);
+        stage_tile<T, D>(dOs, dob, sh.o_ls, q0, sh.Lq);
+        if (threadIdx.x < TILE) {
+            const int qi = q0 + threadIdx.x;
+            const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (qi < sh.Lq ? qi : 0);
+            lse_s[threadIdx.x] = qi < sh.Lq ? lse[si] * LOG2E : INFINITY;  // +inf -> p = 0 for padded queries
+            del_s[threadIdx.x] = qi < sh.Lq ? delta[si] : 0.f;
+        }
+        __syncthreads();
+        f32x4 S[2][4], dP[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const RowFrag<T, D> qf = load_rowfrag<T, D>(Qs + (16 * t + i) * LS, g);
+            const RowFrag<T, D> dof = load_rowfrag<T, D>(dOs + (16 * t + i) * LS, g);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {  // C/D: col = own key (lane & 15), row = query 16t + 4g + reg
+                S[mt][t] = mma_rows<T, D>(qf, kf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                dP[mt][t] = mma_rows<T, D>(dof, vf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float lq = lse_s[16 * t + 4 * g + r], dl = del_s[16 * t + 4 * g + r];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float p = kvalid[mt] ? exp2f(S[mt][t][r] * sl2 - lq) : 0.f;
+                    S[mt][t][r] = p;                                         // P
+                    dP[mt][t][r] = p * (dP[mt][t][r] - dl) * sh.scale;        // dS
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            mma_tr<T, D>(adv[mt], dOs, S[mt], lane);
+            mma_tr<T, D>(adk[mt], Qs, dP[mt], lane);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+        if (krow[mt] < sh.Lk) {
+            const int64_t off = b * sh.kv_bs + (int64_t)krow[mt] * sh.kv_ls + (int64_t)h * D;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                store4T<T>(dk + off + dt * 16 + 4 * g, adk[mt][dt]);
+                store4T<T>(dv + off + dt * 16 + 4 * g, adv[mt][dt]);
+            }
+        }
+}
+
+// ==================================================================================================== host
+static int check_attn(const char* nm, int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls,
+                      int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls) {
+    SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "%s: bad dtype", nm);
+    SEDD_CHECK_ARG(B >= 0 && H > 0 && Lq > 0 && Lk > 0, "%s: bad sizes B=%d H=%d Lq=%d Lk=%d", nm, B, H, Lq, Lk);
+    const int al = dtype == SEDD_BF16 ? 8 : 4;
+    if (!(d == 32 || d == 64 || d == 96 || d == 128) || q_bs % al || q_ls % al || kv_bs % al || kv_ls % al || o_bs % 4 ||
+        o_ls % 4) {
+        sedd_set_error("%s: head dim %d / strides unsupported (d in {32,64,96,128}, strides multiples of %d)", nm, d, al);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    SEDD_CHECK_ARG((int64_t)B * H < 65536, "%s: B*H = %ld exceeds the grid limit 65535", nm, (long)B * H);
+    return SEDD_OK;
+}
+
+#define DISPATCH_ATTN(dtype, d, ...)                                                          \
+    do {                                                                                      \
+        if ((dtype) == SEDD_BF16) {                                                           \
+            using T = bf16_t;                                                                 \
+            if ((d) == 32) { constexpr int D = 32; __VA_ARGS__; }                             \
+            else if ((d) == 64) { constexpr int D = 64; __VA_ARGS__; }                        \
+            else if ((d) == 96) { constexpr int D = 96; __VA_ARGS__; }                        \
+            else { constexpr int D = 128; __VA_ARGS__; }                                      \
+        } else {                                                                              \
+            using T = float;                                                                  \
+            if ((d) == 32) { constexpr int D = 32; __VA_ARGS__; }                             \
+            else if ((d) == 64) { constexpr int D = 64; __VA_ARGS__; }                        \
+            else if ((d) == 96) { constexpr int D = 96; __VA_ARGS__; }                        \
+            else { constexpr int D = 128; __VA_ARGS__; }                                      \
+        }                                                                                     \
+    } while (0)
+
+extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                             const uint8_t* key_mask, int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs,
+                             int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls,
+                             sedd_stream_t stream) {
+    int rc = check_attn("attn_fwd", dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls);
+    if (rc) return rc;
+    if (B == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d)};
+    const dim3 grid((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
+    DISPATCH_ATTN(dtype, d, hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, key_mask, sh));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                             const float* lse, const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta,
+                             int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
+                             int64_t kv_ls, int64_t o_bs, int64_t o_ls, sedd_stream_t stream) {
+    int rc = check_attn("attn_bwd", dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls);
+    if (rc) return rc;
+    if (B == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "attn_bwd: null pointer");
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d)};
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * H * Lq;
+    if (dtype == SEDD_BF16)
+        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3(sedd_grid_for(rows, 256, 256 * 16)), dim3(256), 0, st,
+                           (const bf16_t*)o, (const bf16_t*)dout, delta, B, H, Lq, d, o_bs, o_ls);
+    else
+        hipLaunchKernelGGL((attn_delta_kernel<float>), dim3(sedd_grid_for(rows, 256, 256 * 16)), dim3(256), 0, st,
+                           (const float*)o, (const float*)dout, delta, B, H, Lq, d, o_bs, o_ls);
+    const dim3 gq((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H), gk((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
+    DISPATCH_ATTN(dtype, d, {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                           (const T*)dout, lse, delta, key_mask, (T*)dq, sh);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), gk, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                           (const T*)dout, lse, delta, key_mask, (T*)dk, (T*)dv, sh);
+    });
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
