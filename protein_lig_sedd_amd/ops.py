@@ -150,3 +150,244 @@ def transp_transition(graph, x, sigma):
     check(lib().sedd_transp_transition(graph.code, _p(x), _p(_batch_scalar(sigma, B)), _p(out), M, L, graph.dim,
                                        _stream()), "sedd_transp_transition")
     return out
+
+
+# ------------------------------------------------------------------------------------------- model: pointwise
+def timestep_embedding(sigma, dim=256):
+    sigma = _c(sigma.reshape(-1), torch.float32)
+    out = torch.empty(sigma.numel(), dim, dtype=torch.float32, device=sigma.device)
+    check(lib().sedd_timestep_embedding(_p(sigma), _p(out), sigma.numel(), dim, _stream()), "sedd_timestep_embedding")
+    return out
+
+
+def silu_fwd(x):
+    x = _c(x, torch.float32)
+    y = torch.empty_like(x)
+    check(lib().sedd_silu_fwd(_p(x), _p(y), x.numel(), _stream()), "sedd_silu_fwd")
+    return y
+
+
+def silu_bwd(x, dy):
+    x, dy = _c(x, torch.float32), _c(dy, torch.float32)
+    dx = torch.empty_like(x)
+    check(lib().sedd_silu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "sedd_silu_bwd")
+    return dx
+
+
+def embedding_fwd(table, idx):
+    idx = _c(idx, torch.int64)
+    V, D = table.shape
+    out = torch.empty(*idx.shape, D, dtype=torch.float32, device=table.device)
+    check(lib().sedd_embedding_fwd(_p(table), _p(idx), _p(out), idx.numel(), D, V, _stream()), "sedd_embedding_fwd")
+    return out
+
+
+def embedding_bwd(dout, idx, dtable):
+    """dtable[idx] += dout (in place on dtable, fp32 [V, D])."""
+    idx, dout = _c(idx, torch.int64), _c(dout, torch.float32)
+    V, D = dtable.shape
+    check(lib().sedd_embedding_bwd(_p(dout), _p(idx), _p(dtable), idx.numel(), D, V, _stream()), "sedd_embedding_bwd")
+
+
+def _mod_args(t):
+    """(pointer-able tensor, dtype code, row stride) of a [B, D] view into the adaLN output."""
+    if t is None:
+        return None, F32, 0
+    if t.stride(-1) != 1:
+        raise ValueError("modulation slice must be contiguous in its last dim")
+    return t, _dt(t), t.stride(0)
+
+
+def ln_modulate_fwd(x, w, shift=None, scale=None, bias=None, out_dtype=torch.float32):
+    """x fp32 [B, L, D] -> (y [B, L, D] out_dtype, mean [M], rstd [M]); shift/scale are [B, D] (strided) views."""
+    B, L, D = x.shape
+    M = B * L
+    y = torch.empty(B, L, D, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    sc, mdt, ms = _mod_args(scale)
+    sh, _, _ = _mod_args(shift)
+    check(lib().sedd_ln_modulate_fwd(_p(x), _p(w), _p(bias), _p(sh), _p(sc), mdt, ms, _p(y), _dt(y), _p(mean),
+                                     _p(rstd), M, L, D, _stream()), "sedd_ln_modulate_fwd")
+    return y, mean, rstd
+
+
+def ln_modulate_bwd(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dscale):
+    """dx fp32 [B,L,D] written or accumulated; dw fp32 [D] accumulated (+=); dshift/dscale fp32 [B, D] (strided)
+    views written (may be None)."""
+    B, L, D = x.shape
+    M = B * L
+    nchunk = lib().sedd_ln_bwd_chunks(M, L)
+    ws = torch.empty(3 * nchunk * D, dtype=torch.float32, device=x.device)
+    sc, mdt, ms = _mod_args(scale)
+    check(lib().sedd_ln_modulate_bwd(_p(dy), _dt(dy), _p(x), _p(w), _p(sc), mdt, ms, _p(mean), _p(rstd), _p(dx),
+                                     1 if accumulate else 0, _p(ws), M, L, D, _stream()), "sedd_ln_modulate_bwd")
+    dstride = dshift.stride(0) if dshift is not None else (dscale.stride(0) if dscale is not None else D)
+    check(lib().sedd_ln_modulate_bwd_reduce(_p(ws), _p(dw), _p(dshift), _p(dscale), dstride, M, L, D, _stream()),
+          "sedd_ln_modulate_bwd_reduce")
+
+
+def gate_residual_fwd(residual, a, gate, keep=None, inv_keep=1.0):
+    B, L, D = residual.shape
+    out = torch.empty_like(residual)
+    g, mdt, ms = _mod_args(gate)
+    check(lib().sedd_gate_residual_fwd(_p(residual), _p(a), _dt(a), _p(g), mdt, ms, _p(keep), float(inv_keep), _p(out),
+                                       B * L, L, D, _stream()), "sedd_gate_residual_fwd")
+    return out
+
+
+def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0):
+    """-> da (dtype of a); dgate fp32 [B, D] (strided view) written."""
+    B, L, D = dout.shape
+    M = B * L
+    da = torch.empty_like(a)
+    nchunk = lib().sedd_ln_bwd_chunks(M, L)
+    ws = torch.empty(nchunk * D, dtype=torch.float32, device=dout.device)
+    g, mdt, ms = _mod_args(gate)
+    check(lib().sedd_gate_residual_bwd(_p(dout), _p(a), _dt(a), _p(g), mdt, ms, _p(keep), float(inv_keep), _p(da),
+                                       _p(ws), M, L, D, _stream()), "sedd_gate_residual_bwd")
+    check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), M, L, D, _stream()),
+          "sedd_gate_residual_bwd_reduce")
+    return da
+
+
+def rotary_qkv_(qkv, cos, sin, conj=False):
+    """in place on qkv [B, L, 3, H, d]; cos/sin fp32 [L, d/2]."""
+    B, L, three, H, d = qkv.shape
+    assert three == 3 and qkv.is_contiguous()
+    check(lib().sedd_rotary_qkv(_p(qkv), _dt(qkv), _p(cos), _p(sin), B, L, H, d, 1 if conj else 0, _stream()),
+          "sedd_rotary_qkv")
+    return qkv
+
+
+def gelu_fwd(u):
+    g = torch.empty_like(u)
+    check(lib().sedd_gelu_fwd(_p(u), _p(g), _dt(u), u.numel(), _stream()), "sedd_gelu_fwd")
+    return g
+
+
+def gelu_bwd(u, dg):
+    du = torch.empty_like(u)
+    check(lib().sedd_gelu_bwd(_p(u), _p(dg), _p(du), _dt(u), u.numel(), _stream()), "sedd_gelu_bwd")
+    return du
+
+
+def logits_epilogue_(logits, sigma, idx, scale_by_sigma=True):
+    B = logits.shape[0]
+    V = logits.shape[-1]
+    M = logits.numel() // V
+    check(lib().sedd_logits_epilogue(_p(logits), _dt(logits), _p(_batch_scalar(sigma, B)), _p(_c(idx, torch.int64)),
+                                     1 if scale_by_sigma else 0, M, M // B, V, _stream()), "sedd_logits_epilogue")
+    return logits
+
+
+def logits_epilogue_bwd_(dlogits, idx):
+    V = dlogits.shape[-1]
+    check(lib().sedd_logits_epilogue_bwd(_p(dlogits), _dt(dlogits), _p(_c(idx, torch.int64)), dlogits.numel() // V, V,
+                                         _stream()), "sedd_logits_epilogue_bwd")
+    return dlogits
+
+
+def colsum(a, out=None, accumulate=False):
+    """a [M, N] (row stride allowed) -> fp32 [N]; accumulate into `out` when given and accumulate=True."""
+    M, N = a.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+        accumulate = False
+    check(lib().sedd_colsum(_p(a), _dt(a), a.stride(0), _p(out), 1 if accumulate else 0, M, N, _stream()), "sedd_colsum")
+    return out
+
+
+def transpose(a, out_dtype=None):
+    """a [M, N] (row stride allowed) -> contiguous [N, M] in out_dtype."""
+    M, N = a.shape
+    out = torch.empty(N, M, dtype=out_dtype or a.dtype, device=a.device)
+    check(lib().sedd_transpose(_p(a), _dt(a), a.stride(0), _p(out), _dt(out), M, M, N, _stream()), "sedd_transpose")
+    return out
+
+
+def cast(a, dtype, out=None):
+    a = _c(a)
+    if out is None:
+        out = torch.empty(a.shape, dtype=dtype, device=a.device)
+    check(lib().sedd_cast(_p(a), _dt(a), _p(out), _dt(out), a.numel(), _stream()), "sedd_cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=False, want_pre=False):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(GELU). A, B share dtype (bf16 or fp32), row strides allowed.
+    -> C, or (C, pre) when gelu and want_pre."""
+    M, K = A.shape
+    N, K2 = B.shape
+    if K != K2 or A.dtype != B.dtype:
+        raise ValueError(f"gemm_nt: A {tuple(A.shape)} {A.dtype} vs B {tuple(B.shape)} {B.dtype}")
+    if A.stride(1) != 1 or B.stride(1) != 1:
+        raise ValueError("gemm_nt: operands must be K-contiguous")
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or A.dtype, device=A.device)
+    epi = _L.EPI_NONE if bias is None else (_L.EPI_BIAS_GELU if gelu else _L.EPI_BIAS)
+    if gelu and bias is None:
+        raise ValueError("gemm_nt: GELU epilogue needs a bias")
+    pre = torch.empty_like(out) if (gelu and want_pre) else None
+    check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                             _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
+    return (out, pre) if (gelu and want_pre) else out
+
+
+# --------------------------------------------------------------------------------------------- attention
+def _attn_strides(t):
+    """t: [B, L, H, d] view with contiguous last dim and head stride d -> (batch stride, seq stride)."""
+    if t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+        raise ValueError("attention operands need layout [B, L, H, d] with contiguous (H, d)")
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q, k, v, key_mask=None):
+    """q [B, Lq, H, d], k/v [B, Lk, H, d] (strided views of a packed qkv allowed; k and v share strides).
+    key_mask: optional bool/uint8 [B, Lk], True = attend.  -> (o [B, Lq, H, d] contiguous, lse fp32 [B, H, Lq])."""
+    B, Lq, H, d = q.shape
+    Lk = k.shape[1]
+    qs, ks = _attn_strides(q), _attn_strides(k)
+    if _attn_strides(v) != ks:
+        raise ValueError("k and v must share strides")
+    o = torch.empty(B, Lq, H, d, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    km = None if key_mask is None else _c(key_mask.to(torch.uint8))
+    check(lib().sedd_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(km), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1],
+                              ks[0], ks[1], o.stride(0), o.stride(1), _stream()), "sedd_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None):
+    """dq/dk/dv: preallocated views with the same strides as q/k/v (e.g. slots of a packed dqkv)."""
+    B, Lq, H, d = q.shape
+    Lk = k.shape[1]
+    qs, ks = _attn_strides(q), _attn_strides(k)
+    if _attn_strides(dq) != qs or _attn_strides(dk) != ks or _attn_strides(dv) != ks or _attn_strides(v) != ks:
+        raise ValueError("gradient views must share the strides of their primal tensors")
+    dout = _c(dout)
+    if _attn_strides(dout) != _attn_strides(o):
+        raise ValueError("dout must be laid out like o")
+    delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    km = None if key_mask is None else _c(key_mask.to(torch.uint8))
+    check(lib().sedd_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(km), _p(dq), _p(dk), _p(dv),
+                              _p(delta), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1], ks[0], ks[1], o.stride(0), o.stride(1),
+                              _stream()), "sedd_attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def sumsq_clip(g, gscale=1.0, max_norm=0.0, ws=None, out=None):
+    if ws is None:
+        ws = torch.empty(1024, dtype=torch.float32, device=g.device)
+    if out is None:
+        out = torch.ones(2, dtype=torch.float32, device=g.device)
+    check(lib().sedd_sumsq_clip(_p(g), g.numel(), float(gscale), float(max_norm), _p(ws), _p(out), _stream()),
+          "sedd_sumsq_clip")
+    return out
+
+
+def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, step, ema_decay):
+    check(lib().sedd_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(p_bf16), _p(clip_coef), float(grad_scale),
+                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                    float(ema_decay), p.numel(), _stream()), "sedd_adamw_ema_step")

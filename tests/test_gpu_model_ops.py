@@ -1,0 +1,290 @@
+"""GPU parity of the model kernels (through the C ABI) against plain fp32 torch references of the same op and the CPU
+oracle (oracle/sedd_cpu.py).  Tolerances: fp32 kernels 1e-4 relative (north_star), bf16 kernels 2e-2."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, rel_err
+from oracle import sedd_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from protein_lig_sedd_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (8, 4608, 128), (1024, 26, 768), (64, 64, 8),
+                                   (257, 129, 776)])
+def test_gemm_fp32(M, N, K):
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    A, B = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+    bias = torch.randn(N, device=DEV)
+    ref = A.double() @ B.double().T
+    assert rel_err(ops.gemm_nt(A, B), ref) < 2e-6
+    assert rel_err(ops.gemm_nt(A, B, bias=bias), ref + bias.double()) < 2e-6
+    out, pre = ops.gemm_nt(A, B, bias=bias, gelu=True, want_pre=True)
+    assert rel_err(pre, ref + bias.double()) < 2e-6
+    assert rel_err(out, F.gelu((ref + bias.double()).float(), approximate="tanh")) < 1e-5
+    C = torch.randn(M, N, device=DEV)
+    C0 = C.clone()
+    ops.gemm_nt(A, B, out=C, accumulate=True)
+    assert rel_err(C, C0.double() + ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (64, 4608, 128), (2048, 26, 768), (512, 768, 3072),
+                                   (257, 129, 776)])
+def test_gemm_bf16(M, N, K):
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV).bfloat16()
+    B = torch.randn(N, K, device=DEV).bfloat16()
+    bias = torch.randn(N, device=DEV)
+    ref = A.double() @ B.double().T  # exact products of the bf16 inputs
+    out32 = ops.gemm_nt(A, B, out_dtype=torch.float32)
+    assert rel_err(out32, ref) < 1e-5  # fp32 accumulation of exact bf16 products
+    out = ops.gemm_nt(A, B, bias=bias)
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out, ref + bias.double()) < 5e-3
+    g, pre = ops.gemm_nt(A, B, bias=bias, gelu=True, want_pre=True)
+    assert rel_err(pre, ref + bias.double()) < 5e-3
+    assert rel_err(g, F.gelu(pre.float(), approximate="tanh")) < 5e-3
+    C = torch.randn(M, N, device=DEV)
+    C0 = C.clone()
+    ops.gemm_nt(A, B, out=C, accumulate=True)
+    assert rel_err(C, C0.double() + ref) < 1e-5
+    # strided A (a column slab of a wider matrix) as used for packed activations
+    wide = torch.randn(M, K + 64, device=DEV).bfloat16()
+    assert rel_err(ops.gemm_nt(wide[:, 32:32 + K], B, out_dtype=torch.float32),
+                   wide[:, 32:32 + K].double() @ B.double().T) < 1e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    ops = _ops()
+    from protein_lig_sedd_amd._lib import SeddError
+    with pytest.raises(SeddError):
+        ops.gemm_nt(torch.zeros(4, 12, device=DEV).bfloat16(), torch.zeros(4, 12, device=DEV).bfloat16())
+    with pytest.raises(ValueError):
+        ops.gemm_nt(torch.zeros(4, 16, device=DEV), torch.zeros(4, 8, device=DEV))
+
+
+@pytest.mark.parametrize("B,L,D", [(3, 40, 768), (2, 33, 1024), (2, 5, 64), (1, 128, 1536)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ln_modulate(B, L, D, dtype):
+    ops = _ops()
+    torch.manual_seed(D + L)
+    x = (torch.randn(B, L, D, device=DEV) * 2 + 0.5).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(D, device=DEV)).requires_grad_(True)
+    mod = (0.3 * torch.randn(B, 6 * D, device=DEV)).to(dtype)
+    modr = mod.float().requires_grad_(True)
+    shift, scale = modr[:, :D], modr[:, D:2 * D]
+    ref = F.layer_norm(x, [D]) * w * (1 + scale[:, None]) + shift[:, None]
+    y, mean, rstd = ops.ln_modulate_fwd(x.detach(), w.detach(), shift=mod[:, :D], scale=mod[:, D:2 * D], out_dtype=dtype)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert rel_err(y, ref) < tol
+    dy = torch.randn(B, L, D, device=DEV).to(dtype)
+    ref.backward(dy.float())
+    dx = torch.randn(B, L, D, device=DEV)
+    dx0 = dx.clone()
+    dw = torch.zeros(D, device=DEV)
+    dmod = torch.zeros(B, 6 * D, device=DEV)
+    ops.ln_modulate_bwd(dy, x.detach(), w.detach(), mod[:, D:2 * D], mean, rstd, dx, True, dw, dmod[:, :D], dmod[:, D:2 * D])
+    assert rel_err(dx - dx0, x.grad) < 1e-4
+    assert rel_err(dw, w.grad) < 1e-4
+    assert rel_err(dmod[:, :2 * D], modr.grad[:, :2 * D]) < 1e-4
+    assert float(dmod[:, 2 * D:].abs().max()) == 0.0
+    # plain affine LayerNorm (cross-attention norm)
+    b = torch.randn(D, device=DEV)
+    y2, _, _ = ops.ln_modulate_fwd(x.detach(), w.detach(), bias=b)
+    assert rel_err(y2, F.layer_norm(x.detach(), [D], w.detach(), b)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_residual(dtype):
+    ops = _ops()
+    torch.manual_seed(3)
+    B, L, D = 3, 37, 768
+    res = torch.randn(B, L, D, device=DEV, requires_grad=True)
+    a = torch.randn(B, L, D, device=DEV).to(dtype)
+    ar = a.float().requires_grad_(True)
+    mod = torch.randn(B, 6 * D, device=DEV).to(dtype)
+    gr = mod[:, 2 * D:3 * D].float().requires_grad_(True)
+    keep = (torch.rand(B, L, D, device=DEV) > 0.1).to(torch.uint8)
+    inv = 1 / 0.9
+    for kp in (None, keep):
+        res.grad = ar.grad = gr.grad = None
+        ref = res + gr[:, None] * (ar * (kp.float() * inv if kp is not None else 1.0))
+        out = ops.gate_residual_fwd(res.detach(), a, mod[:, 2 * D:3 * D], kp, inv)
+        assert rel_err(out, ref) < 1e-6
+        dout = torch.randn(B, L, D, device=DEV)
+        ref.backward(dout)
+        dmod = torch.zeros(B, 6 * D, device=DEV)
+        da = ops.gate_residual_bwd(dout, a, mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], kp, inv)
+        assert rel_err(da, ar.grad) < (1e-6 if dtype == torch.float32 else 5e-3)
+        assert rel_err(dmod[:, 2 * D:3 * D], gr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("d", [32, 64, 96])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rotary(d, dtype):
+    ops = _ops()
+    torch.manual_seed(d)
+    B, L, H = 2, 50, 3
+    qkv = torch.randn(B, L, 3, H, d)
+    cos, sin = O.rotary_cos_sin(L, d)
+    q, k, v = qkv.unbind(2)
+    ref = torch.stack([O.apply_rotary(q, cos, sin), O.apply_rotary(k, cos, sin), v], 2)
+    c2, s2 = cos[:, :d // 2].contiguous().to(DEV), sin[:, :d // 2].contiguous().to(DEV)
+    x = qkv.to(DEV).to(dtype).contiguous()
+    ops.rotary_qkv_(x, c2, s2)
+    assert rel_err(x, ref) < (1e-6 if dtype == torch.float32 else 5e-3)
+    ops.rotary_qkv_(x, c2, s2, conj=True)  # conjugate rotation undoes it
+    assert rel_err(x, qkv) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+def test_gelu_silu_embed_epilogue_colsum_transpose():
+    ops = _ops()
+    torch.manual_seed(5)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 5e-3)):
+        u = (torch.randn(1000, 51, device=DEV) * 2).to(dtype)
+        ur = u.float().requires_grad_(True)
+        ref = F.gelu(ur, approximate="tanh")
+        assert rel_err(ops.gelu_fwd(u), ref) < tol
+        dg = torch.randn_like(u)
+        ref.backward(dg.float())
+        assert rel_err(ops.gelu_bwd(u, dg), ur.grad) < max(tol, 2e-6)
+    x = torch.randn(64, 128, device=DEV, requires_grad=True)
+    y = F.silu(x)
+    assert rel_err(ops.silu_fwd(x.detach()), y) < 1e-6
+    dy = torch.randn_like(x)
+    y.backward(dy)
+    assert rel_err(ops.silu_bwd(x.detach(), dy), x.grad) < 1e-6
+    sig = torch.rand(9, device=DEV) * 7
+    assert_close(ops.timestep_embedding(sig, 256), O.timestep_embedding(sig.cpu()), 1e-5, 2e-6)
+    # embedding fwd / scatter-add bwd (small and large vocab)
+    for V in (26, 2365):
+        tab = torch.randn(V, 768, device=DEV)
+        idx = torch.randint(0, V, (5, 333), device=DEV)
+        assert torch.equal(ops.embedding_fwd(tab, idx), tab[idx])
+        dout = torch.randn(5, 333, 768, device=DEV)
+        dt = torch.zeros(V, 768, device=DEV)
+        ops.embedding_bwd(dout, idx, dt)
+        ref = torch.zeros(V, 768, device=DEV).index_add_(0, idx.reshape(-1), dout.reshape(-1, 768))
+        assert rel_err(dt, ref) < 1e-5
+    # logits epilogue
+    for dtype in (torch.float32, torch.bfloat16):
+        lg = torch.randn(4, 33, 26).to(dtype)
+        sg = torch.tensor([0.01, 0.3, 0.7, 5.0])
+        idx = torch.randint(0, 26, (4, 33))
+        ref = O.logits_epilogue(lg, sg, idx)
+        out = ops.logits_epilogue_(lg.to(DEV).clone(), sg.to(DEV), idx.to(DEV))
+        assert rel_err(out.float(), ref.float()) < (1e-6 if dtype == torch.float32 else 8e-3)
+        assert float(out.gather(-1, idx.to(DEV)[..., None]).abs().max()) == 0.0
+        d = ops.logits_epilogue_bwd_(torch.ones(4, 33, 26, device=DEV, dtype=dtype), idx.to(DEV))
+        assert float(d.float().sum()) == 4 * 33 * 25
+    a = torch.randn(777, 130, device=DEV)
+    assert rel_err(ops.colsum(a), a.sum(0)) < 1e-5
+    assert rel_err(ops.colsum(a.bfloat16()), a.bfloat16().float().sum(0)) < 1e-5
+    acc = torch.ones(130, device=DEV)
+    ops.colsum(a, out=acc, accumulate=True)
+    assert rel_err(acc, a.sum(0) + 1) < 1e-5
+    for dt_in, dt_out in ((torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)):
+        a = torch.randn(130, 77, device=DEV).to(dt_in)
+        assert torch.equal(ops.transpose(a, dt_out), a.T.to(dt_out).contiguous())
+    assert torch.equal(ops.cast(a.float(), torch.bfloat16), a.float().bfloat16())
+
+
+def _ref_attn(q, k, v, mask):
+    return O.softmax_attention(q, k, v, mask)
+
+
+@pytest.mark.parametrize("d", [32, 64, 96])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Lq,Lk,masked", [(128, 128, False), (70, 70, False), (100, 45, True), (4, 4, False), (200, 130, True)])
+def test_attention(d, dtype, Lq, Lk, masked):
+    ops = _ops()
+    torch.manual_seed(d + Lq)
+    B, H = 2, 3
+    q = torch.randn(B, Lq, H, d)
+    k = torch.randn(B, Lk, H, d)
+    v = torch.randn(B, Lk, H, d)
+    if dtype == torch.bfloat16:
+        q, k, v = (t.bfloat16().float() for t in (q, k, v))
+    mask = None
+    if masked:
+        mask = torch.rand(B, Lk) > 0.3
+        mask[:, 0] = True
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _ref_attn(qr, kr, vr, mask)
+    dout = torch.randn(B, Lq, H, d)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    ref.backward(dout)
+    qd, kd, vd = (t.to(DEV).to(dtype) for t in (q, k, v))
+    md = None if mask is None else mask.to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, md)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(o, ref) < tol, "o"
+    s = torch.einsum("blhd,bmhd->bhlm", q, k) * d ** -0.5
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    assert_close(lse, torch.logsumexp(s, -1), 1e-4, 1e-4, "lse")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attn_bwd(qd, kd, vd, o, dout.to(DEV).to(dtype), lse, dq, dk, dv, md)
+    tolb = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(dq, qr.grad) < tolb, "dq"
+    assert rel_err(dk, kr.grad) < tolb, "dk"
+    assert rel_err(dv, vr.grad) < tolb, "dv"
+
+
+def test_attention_packed_qkv_and_spike():
+    """packed [B, L, 3, H, d] views (the DDiTBlock layout) and an input that forces the online-softmax rescale
+    (one key row spiked against one query so the running max jumps in a later tile)."""
+    ops = _ops()
+    torch.manual_seed(11)
+    B, L, H, d = 2, 256, 4, 64
+    qkv = torch.randn(B, L, 3, H, d)
+    qkv[0, 200, 1, 2] = qkv[0, 7, 0, 2] * 6  # key 200 (4th tile) aligned with query 7
+    qkv = qkv.bfloat16()
+    x = qkv.to(DEV)
+    o, lse = ops.attn_fwd(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+    ref = _ref_attn(*(qkv.float().unbind(2)), None)
+    assert rel_err(o, ref) < 1e-2
+    assert float((o[0, 7, 2].float().cpu() - ref[0, 7, 2]).abs().max()) < 3e-2
+    dqkv = torch.empty_like(x)
+    dout = torch.randn(B, L, H, d).bfloat16()
+    ops.attn_bwd(x[:, :, 0], x[:, :, 1], x[:, :, 2], o, dout.to(DEV), lse, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
+    qr = qkv.float().requires_grad_(True)
+    _ref_attn(*qr.unbind(2), None).backward(dout.float())
+    assert rel_err(dqkv, qr.grad) < 2e-2
+
+
+def test_optimizer_kernels():
+    ops = _ops()
+    torch.manual_seed(7)
+    n = 4096 * 37 + 8
+    p = torch.randn(n)
+    g = torch.randn(n) * 3
+    m, v, ema = torch.zeros(n), torch.zeros(n), p.clone()
+    pd, gd, md, vd, ed = (t.to(DEV).clone() for t in (p, g, m, v, ema))
+    pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    lr, b1, b2, eps, wd, decay = 3e-4, 0.9, 0.999, 1e-8, 0.01, 0.9999
+    for step in (1, 2, 3):
+        out = ops.sumsq_clip(gd, 1.0, 1.0)
+        gn = float(torch.sqrt((g.double() ** 2).sum()))
+        assert abs(float(out[0]) ** 0.5 - gn) / gn < 1e-5
+        coef = O.clip_coef(gn, 1.0)
+        assert abs(float(out[1]) - coef) / coef < 1e-5
+        O.adamw_step(p, g, m, v, step, lr, b1, b2, eps, wd, coef)
+        O.ema_update(ema, p, O.ema_decay(step, decay))
+        ops.adamw_ema_step(pd, gd, md, vd, ed, pb, out[1:], 1.0, lr, b1, b2, eps, wd, step, O.ema_decay(step, decay))
+        assert_close(pd, p, 1e-5, 1e-6, f"p step {step}")
+        assert_close(md, m, 1e-5, 1e-7)
+        assert_close(vd, v, 1e-5, 1e-9)
+        assert_close(ed, ema, 1e-5, 1e-6)
+        assert torch.equal(pb, pd.bfloat16())
