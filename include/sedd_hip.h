@@ -193,6 +193,12 @@ int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
 int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                         const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float ema_decay, int64_t n, sedd_stream_t stream);
+/* out[0] = sum_r w[r / L] * x[r]  (losses.py:29: (dsigma[:, None] * loss).mean() with w_b = dsigma_b / M).
+ * fp32, deterministic two-stage; ws fp32 [1024] caller workspace. */
+int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L, float* ws, float* out,
+                            sedd_stream_t stream);
+/* model/ema.py:44-52 stand-alone: shadow -= one_minus_decay * (shadow - p), fp32, n elements. */
+int sedd_ema_update(float* shadow, const float* p, float one_minus_decay, int64_t n, sedd_stream_t stream);
 /* out[0] = sum_i g[i]^2 (fp32, deterministic two-stage); ws fp32 [1024] caller workspace.
  * Then, when max_norm > 0: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)). */
 int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float max_norm, float* ws, float* out,

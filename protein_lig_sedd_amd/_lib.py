@@ -51,6 +51,8 @@ SIGNATURES = {
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "i" + "f" + "lp",
     "sedd_sumsq_clip": "plffppp",
+    "sedd_ema_update": "ppflp",
+    "sedd_batch_weighted_sum": "ppllppp",
 }
 
 

@@ -68,6 +68,21 @@ extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v,
     return SEDD_OK;
 }
 
+__global__ void __launch_bounds__(TPB) ema_update_kernel(float* __restrict__ s, const float* __restrict__ p, float omd,
+                                                         int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        s[i] -= omd * (s[i] - p[i]);
+}
+extern "C" int sedd_ema_update(float* shadow, const float* p, float one_minus_decay, int64_t n, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(n >= 0, "ema_update: bad n");
+    if (n == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(shadow && p, "ema_update: null pointer");
+    hipLaunchKernelGGL(ema_update_kernel, dim3(sedd_grid_for(n, TPB, 256 * 16)), dim3(TPB), 0, (hipStream_t)stream, shadow,
+                       p, one_minus_decay, n);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
 // ---- sum of squares, two deterministic stages ---------------------------------------------------------------
 #define SUMSQ_MAX_BLOCKS 1024
 __global__ void __launch_bounds__(TPB) sumsq_stage1(const float* __restrict__ g, int64_t n, float* __restrict__ ws) {
@@ -107,6 +122,29 @@ extern "C" int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float ma
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_stage1, dim3(nb), dim3(TPB), 0, st, g, n, ws);
     hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TPB), 0, st, ws, nb, gscale, max_norm, out);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ---- loss reduction: sum_r w[r / L] * x[r] --------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) wsum_stage1(const float* __restrict__ x, const float* __restrict__ w, int64_t M,
+                                                   int64_t L, float* __restrict__ ws) {
+    __shared__ float red[TPB / 64];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M; i += (int64_t)gridDim.x * TPB) s += w[i / L] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L, float* ws, float* out,
+                                       sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "batch_weighted_sum: bad sizes");
+    SEDD_CHECK_ARG(ws && out && (M == 0 || (x && w)), "batch_weighted_sum: null pointer");
+    const int nb = M == 0 ? 1 : sedd_grid_for(M, TPB * 4, SUMSQ_MAX_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wsum_stage1, dim3(nb), dim3(TPB), 0, st, x, w, M, L, ws);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TPB), 0, st, ws, nb, 1.0f, 0.0f, out);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

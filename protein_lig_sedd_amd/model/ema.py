@@ -1,0 +1,58 @@
+"""Drop-in for protlig_dd/model/ema.py with the update on the HIP EMA kernel (one launch per parameter, or ONE launch
+when the parameters are views of a single flat buffer as the trainer in train.py lays them out)."""
+import torch
+
+from .. import ops
+
+
+class ExponentialMovingAverage:
+    def __init__(self, parameters, decay, use_num_updates=True):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError('Decay must be between 0 and 1')
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
+        self.collected_params = []
+
+    def current_decay(self):
+        """decay that the NEXT update will use after incrementing num_updates (ema.py:38-42)."""
+        decay = self.decay
+        if self.num_updates is not None:
+            decay = min(decay, (1 + self.num_updates + 1) / (10 + self.num_updates + 1))
+        return decay
+
+    def update(self, parameters):
+        """ema.py:32-52"""
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        one_minus_decay = 1.0 - decay
+        with torch.no_grad():
+            parameters = [p for p in parameters if p.requires_grad]
+            for s_param, param in zip(self.shadow_params, parameters):
+                if s_param.is_cuda:
+                    ops.ema_update_(s_param, param.detach().contiguous(), one_minus_decay)
+                else:
+                    raise RuntimeError("ExponentialMovingAverage.update needs CUDA(HIP) parameters: no CPU fallback")
+
+    def copy_to(self, parameters):
+        parameters = [p for p in parameters if p.requires_grad]
+        for s_param, param in zip(self.shadow_params, parameters):
+            if param.requires_grad:
+                param.data.copy_(s_param.data)
+
+    def store(self, parameters):
+        self.collected_params = [param.clone() for param in parameters]
+
+    def restore(self, parameters):
+        for c_param, param in zip(self.collected_params, parameters):
+            param.data.copy_(c_param.data)
+
+    def state_dict(self):
+        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+
+    def load_state_dict(self, state_dict):
+        self.decay = state_dict['decay']
+        self.num_updates = state_dict['num_updates']
+        self.shadow_params = state_dict['shadow_params']

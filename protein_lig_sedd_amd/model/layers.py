@@ -1,0 +1,245 @@
+"""Kernel-level building blocks shared by the SEDD and the dual-track cross-attention models: compute-dtype weight
+caches, Linear forward/backward on the MFMA GEMM, and the hand-written forward+backward of a DDiT block.
+
+Every tensor operation is a HIP kernel reached through ops.py (C ABI); Python only sequences launches and owns the
+saved-activation bookkeeping that torch.autograd would otherwise do.  Gradient convention: if a parameter already has
+a `.grad` tensor (the trainer pre-allocates them as views of one flat buffer) weight gradients are ACCUMULATED into
+it in place by the producing kernel and autograd receives None; otherwise a fresh gradient tensor is returned.
+"""
+import torch
+
+from .. import ops
+
+
+
+def compute_weight(W, dtype, transposed=False):
+    """W (fp32 master parameter [N, K]) in the compute dtype, optionally transposed ([K, N]); cached per parameter
+    version so the cast runs once per optimiser step (what autocast's weight cache does in the reference)."""
+    ent = getattr(W, "_sedd_wc", None)
+    tag = (W._version, W.data_ptr())
+    if ent is None or ent["tag"] != tag:
+        ent = {"tag": tag}
+        W._sedd_wc = ent
+    key = (dtype, transposed)
+    t = ent.get(key)
+    if t is None:
+        Wd = W.detach()
+        if transposed:  # [K, Np]: the out-feature dim (reduction dim of the dgrad GEMM) zero-padded to the MFMA K step
+            t = transpose_padded(Wd, 8 if dtype == torch.bfloat16 else 4, dtype)
+        else:
+            t = Wd if dtype == torch.float32 else ops.cast(Wd, dtype)
+        ent[key] = t
+    return t
+
+
+def set_compute_weight(W, dtype, tensor):
+    """Let the optimiser hand over a compute-dtype copy it produced itself (fused AdamW -> bf16 write)."""
+    W._sedd_wc = {"tag": (W._version, W.data_ptr()), (dtype, False): tensor}
+
+
+def transpose_padded(a, align, out_dtype=None):
+    """a [M, N] -> [N, Mp] with Mp = M rounded up to `align` and a zero tail (the reduction dim of a wgrad GEMM)."""
+    M, N = a.shape
+    Mp = (M + align - 1) // align * align
+    if Mp == M:
+        return ops.transpose(a, out_dtype)
+    out = torch.empty(N, Mp, dtype=out_dtype or a.dtype, device=a.device)
+    out[:, M:].zero_()
+    ops.check(ops.lib().sedd_transpose(a.data_ptr(), ops._dt(a), a.stride(0), out.data_ptr(), ops._dt(out), Mp, M, N,
+                                       ops._stream()), "sedd_transpose")
+    return out
+
+
+def _sink(param):
+    """(grad tensor to accumulate into or None, whether autograd should receive the result)."""
+    return param.grad if (param is not None and param.grad is not None) else None
+
+
+def linear_fwd(x2d, W, bias=None, gelu=False, want_pre=False, out_dtype=None):
+    """nn.Linear forward: x2d [M, K] (compute dtype) @ W[N, K]^T."""
+    return ops.gemm_nt(x2d, compute_weight(W, x2d.dtype), bias=None if bias is None else bias.detach(), gelu=gelu,
+                       want_pre=want_pre, out_dtype=out_dtype)
+
+
+def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
+    """-> (dx [M, K] or None, dW for autograd or None, db for autograd or None)."""
+    align = 8 if dy2d.dtype == torch.bfloat16 else 4
+    dyT = transpose_padded(dy2d, align)
+    xT = transpose_padded(x2d, align)
+    sink = _sink(W)
+    if sink is not None:
+        ops.gemm_nt(dyT, xT, out=sink, accumulate=True)
+        dW = None
+    else:
+        dW = ops.gemm_nt(dyT, xT, out_dtype=torch.float32)
+    db = None
+    if bias is not None:
+        bs = _sink(bias)
+        if bs is not None:
+            ops.colsum(dy2d, out=bs, accumulate=True)
+        else:
+            db = ops.colsum(dy2d)
+    dx = None
+    if need_dx:
+        Wt = compute_weight(W, dy2d.dtype, transposed=True)      # [K, Np]
+        if Wt.shape[1] != dy2d.shape[1] or dy2d.stride(0) % align:  # ragged out-feature dim (e.g. V = 26): pad dy
+            dyp = torch.zeros(dy2d.shape[0], Wt.shape[1], dtype=dy2d.dtype, device=dy2d.device)
+            dyp[:, :dy2d.shape[1]].copy_(dy2d)
+            dy2d = dyp
+        dx = ops.gemm_nt(dy2d, Wt, out_dtype=dx_dtype)
+    return dx, dW, db
+
+
+def _vec_sink(param, D):
+    s = _sink(param)
+    if s is not None:
+        return s, None
+    z = torch.zeros(D, dtype=torch.float32, device=param.device)
+    return z, z
+
+
+def compact_rotary(cos, sin):
+    """reference tables [1, L, 3, 1, d] (rotary.py:17-25) -> contiguous fp32 [L, d/2] halves for the kernel."""
+    d = cos.shape[-1]
+    return (cos[0, :, 0, 0, :d // 2].float().contiguous(), sin[0, :, 0, 0, :d // 2].float().contiguous())
+
+
+def dropout_mask(shape, p, device):
+    keep = torch.empty(shape, dtype=torch.uint8, device=device)
+    keep.bernoulli_(1.0 - p)
+    return keep
+
+
+# ------------------------------------------------------------------------------------------------- DDiT block
+BLOCK_PARAMS = ("norm1.weight", "attn_qkv.weight", "attn_out.weight", "norm2.weight", "mlp.0.weight", "mlp.0.bias",
+                "mlp.2.weight", "mlp.2.bias", "adaLN_modulation.weight", "adaLN_modulation.bias")
+
+
+def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
+    """DDiTBlock.forward (model/transformer.py:153-189).  x fp32 [B, L, D]; c fp32 [B, C]; P: dict of the block's
+    parameters by reference name; cos/sin compact rotary tables.  Returns x_out fp32 and (if save) the saved state."""
+    B, L, D = x.shape
+    M, H, d = B * L, n_heads, D // n_heads
+    c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+    mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 6D]
+    w1, w2 = P["norm1.weight"].detach(), P["norm2.weight"].detach()
+    h1, mean1, rstd1 = ops.ln_modulate_fwd(x, w1, shift=mod[:, :D], scale=mod[:, D:2 * D], out_dtype=cdt)
+    qkv = linear_fwd(h1.view(M, D), P["attn_qkv.weight"]).view(B, L, 3, H, d)
+    ops.rotary_qkv_(qkv, cos, sin)
+    o, lse = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+    a = linear_fwd(o.view(M, D), P["attn_out.weight"]).view(B, L, D)
+    inv = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+    keep1 = dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
+    x1 = ops.gate_residual_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv)
+    h2, mean2, rstd2 = ops.ln_modulate_fwd(x1, w2, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=cdt)
+    if save:
+        g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True, want_pre=True)
+    else:
+        g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True), None
+    y = linear_fwd(g, P["mlp.2.weight"], P["mlp.2.bias"]).view(B, L, D)
+    keep2 = dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
+    x2 = ops.gate_residual_fwd(x1, y, mod[:, 5 * D:6 * D], keep2, inv)
+    st = None
+    if save:
+        st = dict(x=x, c_c=c_c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
+                  x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, g=g, y=y, keep2=keep2, inv=inv, cos=cos, sin=sin)
+    return x2, st
+
+
+def ddit_block_backward(dx2, st, P, n_heads):
+    """-> (dx fp32 [B,L,D], dc fp32 [B,C], {param name: grad or None})"""
+    x = st["x"]
+    B, L, D = x.shape
+    M, H, d = B * L, n_heads, D // n_heads
+    mod, cdt = st["mod"], st["h1"].dtype
+    grads = {}
+    dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
+    dx = dx2.clone()
+    # ---- MLP branch: x2 = x1 + gate_mlp * dropout(mlp(modulate(LN(x1))))
+    dy = ops.gate_residual_bwd(dx, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
+    dg, grads["mlp.2.weight"], grads["mlp.2.bias"] = linear_bwd(st["g"], dy, P["mlp.2.weight"], P["mlp.2.bias"])
+    du = ops.gelu_bwd(st["u"], dg)
+    dh2, grads["mlp.0.weight"], grads["mlp.0.bias"] = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], P["mlp.0.bias"])
+    dw2, grads["norm2.weight"] = _vec_sink(P["norm2.weight"], D)
+    ops.ln_modulate_bwd(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],
+                        st["rstd2"], dx, True, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
+    # ---- attention branch: x1 = x + gate_msa * dropout(attn_out(attn(rotary(qkv(modulate(LN(x)))))))
+    da = ops.gate_residual_bwd(dx, st["a"], mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], st["keep1"], st["inv"]).view(M, D)
+    do, grads["attn_out.weight"], _ = linear_bwd(st["o"].view(M, D), da, P["attn_out.weight"])
+    qkv = st["qkv"]
+    dqkv = torch.empty_like(qkv)
+    ops.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], st["o"], do.view(B, L, H, d), st["lse"], dqkv[:, :, 0],
+                 dqkv[:, :, 1], dqkv[:, :, 2])
+    ops.rotary_qkv_(dqkv, st["cos"], st["sin"], conj=True)
+    dh1, grads["attn_qkv.weight"], _ = linear_bwd(st["h1"].view(M, D), dqkv.view(M, 3 * D), P["attn_qkv.weight"])
+    dw1, grads["norm1.weight"] = _vec_sink(P["norm1.weight"], D)
+    ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],
+                        dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D])
+    # ---- adaLN: mod = Linear(c)
+    dmod_c = dmod if cdt == torch.float32 else ops.cast(dmod, cdt)
+    dc, grads["adaLN_modulation.weight"], grads["adaLN_modulation.bias"] = linear_bwd(
+        st["c_c"], dmod_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], dx_dtype=torch.float32)
+    return dx, dc, grads
+
+
+# ------------------------------------------------------------------------------------------------ final layer
+FINAL_PARAMS = ("norm_final.weight", "linear.weight", "linear.bias", "adaLN_modulation.weight", "adaLN_modulation.bias")
+
+
+def final_layer_forward(x, c, P, cdt, save):
+    """DDitFinalLayer.forward (model/transformer.py:234-238) -> logits [B, L, V] in the compute dtype."""
+    B, L, D = x.shape
+    M = B * L
+    c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+    mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 2D]
+    h, mean, rstd = ops.ln_modulate_fwd(x, P["norm_final.weight"].detach(), shift=mod[:, :D], scale=mod[:, D:2 * D],
+                                        out_dtype=cdt)
+    logits = linear_fwd(h.view(M, D), P["linear.weight"], P["linear.bias"]).view(B, L, -1)
+    st = dict(x=x, c_c=c_c, mod=mod, h=h, mean=mean, rstd=rstd) if save else None
+    return logits, st
+
+
+def final_layer_backward(dlogits, st, P):
+    x = st["x"]
+    B, L, D = x.shape
+    M = B * L
+    mod, cdt = st["mod"], st["h"].dtype
+    grads = {}
+    dl = dlogits.reshape(M, -1)
+    if dl.dtype != cdt:
+        dl = ops.cast(dl, cdt)
+    dh, grads["linear.weight"], grads["linear.bias"] = linear_bwd(st["h"].view(M, D), dl, P["linear.weight"], P["linear.bias"])
+    dmod = torch.empty(B, 2 * D, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dw, grads["norm_final.weight"] = _vec_sink(P["norm_final.weight"], D)
+    ops.ln_modulate_bwd(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"], st["rstd"], dx,
+                        False, dw, dmod[:, :D], dmod[:, D:2 * D])
+    dmod_c = dmod if cdt == torch.float32 else ops.cast(dmod, cdt)
+    dc, grads["adaLN_modulation.weight"], grads["adaLN_modulation.bias"] = linear_bwd(
+        st["c_c"], dmod_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], dx_dtype=torch.float32)
+    return dx, dc, grads
+
+
+# ------------------------------------------------------------------------------------------- sigma embedding
+SIGMA_PARAMS = ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias")
+
+
+def sigma_map_forward(sigma, P, freq_dim, outer_silu, save):
+    """TimestepEmbedder.forward (transformer.py:91-94), optionally fused with the caller's F.silu (:285). fp32."""
+    emb = ops.timestep_embedding(sigma, freq_dim)
+    h0 = linear_fwd(emb, P["mlp.0.weight"], P["mlp.0.bias"])
+    s0 = ops.silu_fwd(h0)
+    h1 = linear_fwd(s0, P["mlp.2.weight"], P["mlp.2.bias"])
+    out = ops.silu_fwd(h1) if outer_silu else h1
+    st = dict(emb=emb, h0=h0, s0=s0, h1=h1, outer=outer_silu) if save else None
+    return out, st
+
+
+def sigma_map_backward(dout, st, P):
+    grads = {}
+    dh1 = ops.silu_bwd(st["h1"], dout) if st["outer"] else dout.contiguous()
+    ds0, grads["mlp.2.weight"], grads["mlp.2.bias"] = linear_bwd(st["s0"], dh1, P["mlp.2.weight"], P["mlp.2.bias"])
+    dh0 = ops.silu_bwd(st["h0"], ds0)
+    _, grads["mlp.0.weight"], grads["mlp.0.bias"] = linear_bwd(st["emb"], dh0, P["mlp.0.weight"], P["mlp.0.bias"],
+                                                               need_dx=False)
+    return grads

@@ -391,3 +391,19 @@ def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, be
     check(lib().sedd_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(p_bf16), _p(clip_coef), float(grad_scale),
                                     float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
                                     float(ema_decay), p.numel(), _stream()), "sedd_adamw_ema_step")
+
+
+def ema_update_(shadow, p, one_minus_decay):
+    check(lib().sedd_ema_update(_p(shadow), _p(p), float(one_minus_decay), shadow.numel(), _stream()), "sedd_ema_update")
+    return shadow
+
+
+def batch_weighted_sum(x, w):
+    """x fp32 [B, L], w fp32 [B] -> 0-dim fp32 tensor sum_b w_b * sum_l x[b, l]."""
+    B = x.shape[0]
+    M = x.numel()
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(lib().sedd_batch_weighted_sum(_p(_c(x, torch.float32)), _p(_batch_scalar(w, B)), M, M // B, _p(ws), _p(out),
+                                        _stream()), "sedd_batch_weighted_sum")
+    return out[0]

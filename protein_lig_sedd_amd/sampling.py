@@ -1,0 +1,162 @@
+"""Drop-in for protlig_dd/sampling/sampling.py: predictor registry, Euler / Analytic / None predictors, Denoiser,
+get_pc_sampler / get_sampling_fn — with each update step running as ONE fused HIP kernel on the model's log-score
+(exp -> reverse rate | staggered score x transposed transition -> Gumbel arg-max; csrc/graph_ops.hip).
+
+Differences from the reference, all additive:
+  * `u=` (optional) on every update_fn and `noise_seq=` on pc_sampler supply the uniform noise, so identical noise
+    tensors give bit-identical indices (north_star); default None draws torch.rand on the device.
+  * the score model may be either the dual-track cross model (keyword call with `mode=task`, sampling.py:64-76) or a
+    plain SEDD (`model(x, sigma)`); the reference's loop only supports the former.
+  * AnalyticPredictor accepts both its upstream positional signature `update_fn(score_fn, x, t, step_size)` and the
+    keyword signature pc_sampler uses, so `predictor="analytic"` works through get_pc_sampler (in
+    the reference that call raises TypeError).
+"""
+import abc
+import inspect
+
+import torch
+
+from . import _lib as _L
+from .catsample import sample_categorical
+
+_PREDICTORS = {}
+
+
+def register_predictor(cls=None, *, name=None):
+    """A decorator for registering predictor classes (sampling.py:11-28)."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _PREDICTORS:
+            raise ValueError(f'Already registered model with name: {local_name}')
+        _PREDICTORS[local_name] = cls
+        return cls
+
+    if cls is None:
+        return _register
+    return _register(cls)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def _is_dual_track(model):
+    try:
+        params = inspect.signature(model.forward).parameters
+    except (TypeError, ValueError):
+        return False
+    return "mode" in params and "timesteps" in params
+
+
+def model_log_score(score_model, x, sigma, task=None, prot_indices=None, lig_indices=None):
+    """The model call of sampling.py:64-76 / :110-122, returning the LOG score."""
+    if hasattr(score_model, "eval"):
+        score_model.eval()
+    if _is_dual_track(score_model):
+        if task in ("ligand_given_protein", "ligand_only"):
+            return score_model(ligand_indices=x, protein_indices=prot_indices, timesteps=sigma.reshape(-1), mode=task)
+        elif task in ("protein_given_ligand", "protein_only"):
+            return score_model(protein_indices=x, ligand_indices=lig_indices, timesteps=sigma.reshape(-1), mode=task)
+        raise ValueError(f"Invalid mode: {task}")
+    return score_model(x, sigma.reshape(-1))
+
+
+class Predictor(abc.ABC):
+    """The abstract class for a predictor algorithm (sampling.py:36-56)."""
+
+    def __init__(self, graph, noise):
+        super().__init__()
+        self.graph = graph
+        self.noise = noise
+
+    @abc.abstractmethod
+    def update_fn(self, score_model, x, t, step_size, task=None, prot_indices=None, lig_indices=None, u=None):
+        pass
+
+
+@register_predictor(name="euler")
+class EulerPredictor(Predictor):
+    """sampling.py:59-80"""
+
+    def update_fn(self, score_model, x, t, step_size, task=None, prot_indices=None, lig_indices=None, u=None):
+        sigma, dsigma = self.noise(t)
+        log_score = model_log_score(score_model, x, sigma, task, prot_indices, lig_indices)
+        return self.graph.predictor_step(_L.STEP_EULER, log_score, x, step_size * dsigma, u=u)
+
+
+@register_predictor(name="none")
+class NonePredictor(Predictor):
+    """sampling.py:82-85"""
+
+    def update_fn(self, score_fn=None, x=None, t=None, step_size=None, *args, score_model=None, **kw):
+        return x
+
+
+@register_predictor(name="analytic")
+class AnalyticPredictor(Predictor):
+    """sampling.py:88-99"""
+
+    def update_fn(self, score_fn=None, x=None, t=None, step_size=None, task=None, prot_indices=None, lig_indices=None,
+                  u=None, score_model=None):
+        curr_sigma = self.noise(t)[0]
+        next_sigma = self.noise(t - step_size)[0]
+        dsigma = curr_sigma - next_sigma
+        if score_model is not None:  # pc_sampler's keyword call: fused kernel on the model's log-score
+            log_score = model_log_score(score_model, x, curr_sigma, task, prot_indices, lig_indices)
+            return self.graph.predictor_step(_L.STEP_ANALYTIC, log_score, x, dsigma, u=u)
+        # upstream call: score_fn returns the (exponentiated) score -> Graph-method kernels
+        score = score_fn(x, curr_sigma)
+        stag_score = self.graph.staggered_score(score, dsigma)
+        probs = stag_score * self.graph.transp_transition(x, dsigma)
+        return sample_categorical(probs, u=u)
+
+
+class Denoiser:
+    """sampling.py:102-132"""
+
+    def __init__(self, graph, noise):
+        self.graph = graph
+        self.noise = noise
+
+    def update_fn(self, score_model, x, t, step_size=None, task=None, prot_indices=None, lig_indices=None, u=None):
+        sigma = self.noise(t)[0]
+        log_score = model_log_score(score_model, x, sigma, task, prot_indices, lig_indices)
+        return self.graph.predictor_step(_L.STEP_DENOISE, log_score, x, sigma, u=u)
+
+
+def get_sampling_fn(config, graph, noise, batch_dims, eps, device):
+    """sampling.py:135-146"""
+    return get_pc_sampler(graph=graph, noise=noise, batch_dims=batch_dims, predictor=config.sampling.predictor,
+                          steps=config.sampling.steps, denoise=config.sampling.noise_removal, eps=eps, device=device)
+
+
+def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps=1e-5, device=torch.device('cpu'),
+                   proj_fun=lambda x: x):
+    """sampling.py:149-175"""
+    predictor = get_predictor(predictor)(graph, noise)
+    projector = proj_fun
+    denoiser = Denoiser(graph, noise)
+
+    @torch.no_grad()
+    def pc_sampler(model, task=None, prot_indices=None, lig_indices=None, noise_seq=None, x_init=None):
+        """noise_seq: optional sequence of `steps` (+1 when denoising) uniform tensors, one per update."""
+        x = graph.sample_limit(*batch_dims).to(device) if x_init is None else x_init.to(device)
+        timesteps = torch.linspace(1, eps, steps + 1, device=device)
+        dt = (1 - eps) / steps
+        ones = torch.ones(x.shape[0], 1, device=device)
+        for i in range(steps):
+            t = timesteps[i] * ones
+            x = projector(x)
+            u = None if noise_seq is None else noise_seq[i]
+            x = predictor.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
+                                    lig_indices=lig_indices, u=u)
+        if denoise:
+            x = projector(x)
+            t = timesteps[-1] * ones
+            u = None if noise_seq is None else noise_seq[steps]
+            x = denoiser.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
+                                   lig_indices=lig_indices, u=u)
+        return x
+
+    return pc_sampler
