@@ -1,0 +1,198 @@
+"""Headline benchmark: train tokens/s of the SEDD hot path on N MI355X GPUs (BASELINE.json `metric`), one process per
+GPU (torch.distributed.run, RCCL).  Workload = BASELINE.json configs[1]: SEDD small (D=768, 12 blocks, 12 heads,
+cond 128, ~92 M params), absorbing graph, 25-token AA vocab (V=26), L=512, bf16 compute, per-GPU batch 64, AdamW +
+warm-up + clip 1.0 + EMA, dropout 0.1 — synthetic token ids, random-init weights (N(0, 0.02) also for the reference's
+zero-initialised adaLN / output weights so every path is numerically live).
+
+A step = one full train step (corrupt -> forward -> score-entropy loss -> backward -> gradient all-reduce ->
+clip/AdamW/EMA).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md chip table)
+PEAK_HBM_GBS = 8000.0
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def small_config(dropout=0.1):
+    return ns(tokens=25, graph=ns(type="absorb"),
+              model=ns(hidden_size=768, cond_dim=128, n_heads=12, n_blocks=12, dropout=dropout, scale_by_sigma=True))
+
+
+def randomize(model, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2 or name.endswith("bias"):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/sedd_cpu.py, kind "port": a plain-PyTorch fp32 restatement of the reference's train step)
+    timed on this host's cores on a bounded sample of the same workload: same model, L=512, batch 2."""
+    from oracle import sedd_cpu as O
+    from oracle.weights import seeded_state_dict
+    torch.manual_seed(0)
+    D, H, C, nb, tokens, B, L = 768, 12, 128, 12, 25, 2, 512
+    shapes = {"vocab_embed.embedding.weight": (tokens + 1, D), "sigma_map.mlp.0.weight": (C, 256),
+              "sigma_map.mlp.0.bias": (C,), "sigma_map.mlp.2.weight": (C, C), "sigma_map.mlp.2.bias": (C,),
+              "output_layer.norm_final.weight": (D,), "output_layer.linear.weight": (tokens + 1, D),
+              "output_layer.linear.bias": (tokens + 1,), "output_layer.adaLN_modulation.weight": (2 * D, C),
+              "output_layer.adaLN_modulation.bias": (2 * D,)}
+    for i in range(nb):
+        for k, v in {"norm1.weight": (D,), "norm2.weight": (D,), "attn_qkv.weight": (3 * D, D), "attn_out.weight": (D, D),
+                     "mlp.0.weight": (4 * D, D), "mlp.0.bias": (4 * D,), "mlp.2.weight": (D, 4 * D), "mlp.2.bias": (D,),
+                     "adaLN_modulation.weight": (6 * D, C), "adaLN_modulation.bias": (6 * D,)}.items():
+            shapes[f"blocks.{i}.{k}"] = v
+    sd = {k: v.requires_grad_(True) for k, v in seeded_state_dict(shapes, seed=0).items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    ema = {k: v.detach().clone() for k, v in sd.items()}
+    graph, noise = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
+
+    def step(s):
+        x0 = torch.randint(0, tokens, (B, L))
+        t = torch.rand(B) * 0.999 + 1e-3
+        xt = graph.sample_transition(x0, noise(t)[0][:, None], torch.rand(B, L))
+        for p in sd.values():
+            p.grad = None
+        loss, _ = O.sedd_loss(sd, graph, noise, x0, t, xt, H, nb)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values()))
+        coef = O.clip_coef(gn, 1.0)
+        with torch.no_grad():
+            for k, p in sd.items():
+                O.adamw_step(p, p.grad, m[k], v2[k], s, 3e-4, clip_coef=coef)
+                O.ema_update(ema[k], p, O.ema_decay(s, 0.9999))
+
+    step(1)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+        step(n + 2)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * L * n / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of the same model at batch {B} x L {L}, fp32, oracle/sedd_cpu.py + AdamW/EMA"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-steps", type=int, default=8, help="Analytic sampler steps timed for the seqs/s side metric")
+    args = ap.parse_args()
+
+    from protein_lig_sedd_amd import graph_lib, noise_lib, ops, sampling
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer, init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234)  # identical weights on every rank
+    cfg = small_config()
+    model = _SEDD(cfg, compute_dtype=torch.bfloat16).to(dev)
+    randomize(model, 1234)
+    nparams = sum(p.numel() for p in model.parameters())
+    graph, noise = graph_lib.Absorbing(cfg.tokens), noise_lib.LogLinearNoise(eps=1e-3).to(dev)
+    trainer = SEDDTrainer(model, noise, graph, dict(lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                                                    warmup=2500, grad_clip=1.0), ema_decay=0.9999, world_size=world)
+    B, L = args.batch, args.seq
+    torch.manual_seed(1234 + rank)  # per-rank data / noise
+    batches = [torch.randint(0, cfg.tokens, (B, L), device=dev) for _ in range(4)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step(batches[i % 4])
+    sync()
+    ops.PROF = ops.KernelProf()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(batches[i % 4])
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.PROF.summary()
+    ops.PROF = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    tokens_per_s = world * B * L * args.steps / dt
+
+    # side metric: sampled sequences/s (Analytic predictor, batch = per-GPU shard, L = seq), bf16 model forward
+    samp = None
+    if args.sample_steps > 0:
+        model.eval()
+        sampler = sampling.get_pc_sampler(graph, noise, (B, L), "analytic", args.sample_steps, denoise=True, device=dev)
+        sampler(model)
+        sync()
+        ops.PROF = ops.KernelProf()
+        t1 = time.perf_counter()
+        sampler(model)
+        sync()
+        ds = time.perf_counter() - t1
+        sprof = ops.PROF.summary()
+        ops.PROF = None
+        n_l, ms_l, by_l = sprof.get("predictor_step", (0, 0.0, 0.0))
+        samp = {"sampler_model_evals_per_s": world * (args.sample_steps + 1) / ds * B,
+                "seqs_per_s_at_1024_steps": world * B / (ds / (args.sample_steps + 1) * 1025),
+                "predictor_step": {"launches": n_l, "avg_us": 1e3 * ms_l / max(n_l, 1),
+                                   "achieved_GBs": by_l / max(ms_l, 1e-9) / 1e6,
+                                   "frac_hbm_peak": by_l / max(ms_l, 1e-9) / 1e6 / PEAK_HBM_GBS}}
+
+    if rank == 0:
+        n_g, ms_g, fl_g = prof.get("gemm_bf16_nt", (0, 0.0, 0.0))
+        ach = fl_g / max(ms_g, 1e-9) / 1e9  # TFLOP/s
+        others = {k: {"launches": v[0], "ms_per_step": v[1] / args.steps,
+                      "rate": v[2] / max(v[1], 1e-9) / 1e9} for k, v in prof.items()}
+        out = {
+            "metric": "train tokens/sec", "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SEDD small (D768 x 12 blocks, 12 heads, V=26), L=512, "
+                                   "bf16, per-GPU batch %d, AdamW+EMA, dropout 0.1, dp%d" % (B, world),
+                       "global_batch": B * world, "seq_len": L, "params": nparams, "parallelism": f"dp{world}"},
+            "loss": float(loss),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all Linear fwd/dgrad/wgrad launches)",
+                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches_per_step": n_g / max(args.steps, 1),
+                         "avg_launch_us": 1e3 * ms_g / max(n_g, 1),
+                         "gemm_ms_per_step": ms_g / max(args.steps, 1)},
+            "kernels": others,
+        }
+        if samp:
+            out["sampling"] = samp
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,13 +120,16 @@ class _DDiTBlockFn(torch.autograd.Function):
         P = dict(zip(Lyr.BLOCK_PARAMS, params))
         p = blk.dropout if blk.training else 0.0
         out, st = Lyr.ddit_block_forward(x.contiguous(), c.contiguous(), P, blk.n_heads, cos, sin, p, blk.compute_dtype, save)
-        ctx.st, ctx.P, ctx.n_heads = st, P, blk.n_heads
+        ctx.st, ctx.P, ctx.n_heads, ctx.blk = st, P, blk.n_heads, blk
         return out
 
     @staticmethod
     def backward(ctx, dout):
         dx, dc, grads = Lyr.ddit_block_backward(dout.contiguous(), ctx.st, ctx.P, ctx.n_heads)
         ctx.st = None
+        cb = getattr(ctx.blk, "_on_grads_ready", None)  # trainer hook: this block's gradient bucket is complete
+        if cb is not None:
+            cb()
         return (dx, dc, None, None, None, None) + _ret(grads, Lyr.BLOCK_PARAMS)
 
 

@@ -6,6 +6,45 @@ from . import _lib as _L
 from ._lib import ABSORB, BF16, F32, UNIFORM, check, lib  # noqa: F401
 
 
+class KernelProf:
+    """Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figures)."""
+
+    def __init__(self):
+        self.recs = {}
+
+    def add(self, name, start, end, work):
+        self.recs.setdefault(name, []).append((start, end, work))
+
+    def summary(self):
+        """name -> (launches, total ms, total work); call after a device synchronize."""
+        out = {}
+        for name, rs in self.recs.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in rs)
+            out[name] = (len(rs), ms, sum(w for _, _, w in rs))
+        return out
+
+
+PROF = None  # set to a KernelProf to time instrumented launches
+
+
+class _Timed:
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if PROF is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROF is not None:
+            self.e.record()
+            PROF.add(self.name, self.s, self.e, self.work)
+        return False
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
@@ -77,9 +116,11 @@ def score_entropy_fwd(graph, score, sigma, x, x0, gw=None):
     B, M, L = _rows(x)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     ds = torch.empty_like(score) if gw is not None else None
-    check(lib().sedd_score_entropy_fwd(graph.code, _p(score), _dt(score), _p(_batch_scalar(sigma, B)), _p(x), _p(x0),
-                                       _p(out), _p(ds), _p(None if gw is None else _batch_scalar(gw, B)), M, L,
-                                       score.shape[-1], _stream()), "sedd_score_entropy_fwd")
+    V = score.shape[-1]
+    with _Timed("score_entropy", float(M) * ((2 if gw is not None else 1) * V * score.element_size() + 20)):
+        check(lib().sedd_score_entropy_fwd(graph.code, _p(score), _dt(score), _p(_batch_scalar(sigma, B)), _p(x),
+                                           _p(x0), _p(out), _p(ds), _p(None if gw is None else _batch_scalar(gw, B)),
+                                           M, L, V, _stream()), "sedd_score_entropy_fwd")
     return out, ds
 
 
@@ -113,8 +154,10 @@ def predictor_step(graph, step, logscore, x, coef, u):
     if u.shape[-1] != Vu or u.numel() != M * Vu:
         raise ValueError(f"noise tensor must be [..., {Vu}] with {M} rows, got {tuple(u.shape)}")
     out = torch.empty_like(x)
-    check(lib().sedd_predictor_step(graph.code, step, _p(logscore), _dt(logscore), _p(x), _p(_batch_scalar(coef, B)),
-                                    _p(u), _p(out), M, L, V, _stream()), "sedd_predictor_step")
+    with _Timed("predictor_step", float(M) * (V * logscore.element_size() + Vu * 4 + 16)):
+        check(lib().sedd_predictor_step(graph.code, step, _p(logscore), _dt(logscore), _p(x),
+                                        _p(_batch_scalar(coef, B)), _p(u), _p(out), M, L, V, _stream()),
+              "sedd_predictor_step")
     return out
 
 
@@ -330,8 +373,9 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
     if gelu and bias is None:
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
-    check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                             _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
+    with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                 _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
     return (out, pre) if (gelu and want_pre) else out
 
 
@@ -354,8 +398,9 @@ def attn_fwd(q, k, v, key_mask=None):
     o = torch.empty(B, Lq, H, d, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     km = None if key_mask is None else _c(key_mask.to(torch.uint8))
-    check(lib().sedd_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(km), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1],
-                              ks[0], ks[1], o.stride(0), o.stride(1), _stream()), "sedd_attn_fwd")
+    with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * d):
+        check(lib().sedd_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(km), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1],
+                                  ks[0], ks[1], o.stride(0), o.stride(1), _stream()), "sedd_attn_fwd")
     return o, lse
 
 
@@ -371,9 +416,10 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None):
         raise ValueError("dout must be laid out like o")
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     km = None if key_mask is None else _c(key_mask.to(torch.uint8))
-    check(lib().sedd_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(km), _p(dq), _p(dk), _p(dv),
-                              _p(delta), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1], ks[0], ks[1], o.stride(0), o.stride(1),
-                              _stream()), "sedd_attn_bwd")
+    with _Timed("attn_bwd", 10.0 * B * H * Lq * Lk * d):
+        check(lib().sedd_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(km), _p(dq), _p(dk), _p(dv),
+                                  _p(delta), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1], ks[0], ks[1], o.stride(0),
+                                  o.stride(1), _stream()), "sedd_attn_bwd")
 
 
 # ------------------------------------------------------------------------------------------ optimiser

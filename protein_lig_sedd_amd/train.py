@@ -1,0 +1,239 @@
+"""Data-parallel training step for the SEDD hot path — the MI355X-native replacement of the reference's `config_ddp`
+path (training/run_train_ddp_protlig_transf.py:160-165 NCCL init, :196-197 DDP wrap, :284-285 step + loss all-reduce;
+processing/losses.py:49-117 warm-up / clip / AdamW / EMA).
+
+Design (one process per GPU, torch.distributed backend "nccl" == RCCL over xGMI):
+  * all parameters live in ONE flat fp32 buffer (each tensor padded to 64 elements); gradients, Adam moments, the EMA
+    shadow and the bf16 compute copy are flat buffers of the same layout.  param.data / param.grad are views, so the
+    backward kernels accumulate weight gradients straight into the flat gradient buffer;
+  * the gradient buffer is all-reduced in per-block buckets that are launched asynchronously as soon as a block's
+    backward has finished (overlaps RCCL with the remaining backward), then one deterministic norm reduction, then
+    ONE fused kernel does clip -> AdamW -> EMA -> bf16 weight copy over the whole model (sedd_adamw_ema_step) instead
+    of the reference's per-parameter optimizer / EMA loops;
+  * no DDP wrapper, no GradScaler (bf16 needs no loss scaling; the reference's scaler is a no-op numerically).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .losses import get_loss_fn
+from .model import layers as Lyr
+from .model.ema import ExponentialMovingAverage
+
+ALIGN = 64
+
+
+class FlatState:
+    """Flat parameter / gradient / optimiser-state buffers for a list of parameters."""
+
+    def __init__(self, params, compute_dtype=torch.bfloat16, with_ema=True):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.n = n
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.compute_dtype = compute_dtype
+        self.pc = torch.zeros(n, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        for p, off in zip(self.params, self.offsets):
+            view = self.p[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.g[off:off + p.numel()].view(p.shape)
+        self.ema = self.p.clone() if with_ema else None
+        if self.pc is not None:
+            ops.cast(self.p, torch.bfloat16, out=self.pc)
+        self.refresh_compute_weights()
+
+    def view(self, flat, i):
+        p, off = self.params[i], self.offsets[i]
+        return flat[off:off + p.numel()].view(p.shape)
+
+    def refresh_compute_weights(self):
+        """(re)attach the compute-dtype copies after the flat buffers changed behind autograd's back."""
+        for i, p in enumerate(self.params):
+            if p.dim() == 2:
+                Lyr.set_compute_weight(p, self.compute_dtype, p.detach() if self.pc is None else self.view(self.pc, i))
+
+    def ema_params(self):
+        return [self.view(self.ema, i) for i in range(len(self.params))]
+
+
+def init_distributed():
+    """Bootstrap from torch.distributed.run's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as
+    run_train_ddp_protlig_transf.py:160-163 does; backend "nccl" is RCCL on ROCm."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local, world
+
+
+class SEDDTrainer:
+    """loss_fn(model, batch) -> backward -> bucketed RCCL all-reduce -> fused clip/AdamW/EMA step.
+
+    optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
+
+    def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
+                 process_group=None, overlap=True):
+        g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
+        self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
+        self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
+        self.warmup, self.grad_clip = g("warmup", 0), g("grad_clip", 1.0)
+        self.model, self.noise, self.graph = model, noise, graph
+        self.pg = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        cdt = getattr(model, "compute_dtype", torch.float32)
+        self.flat = FlatState(list(model.parameters()), cdt, with_ema=True)
+        self.ema_decay = ema_decay
+        self.ema = ExponentialMovingAverage([], ema_decay)
+        self.ema.shadow_params = self.flat.ema_params()
+        self.loss_fn = get_loss_fn(noise, graph, train=True, sampling_eps=sampling_eps)
+        self.step_count = 0
+        dev = self.flat.p.device
+        self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._norm = torch.ones(2, dtype=torch.float32, device=dev)
+        self.overlap = overlap and self.world > 1
+        self._pending = []
+        self._buckets = self._make_buckets()
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    # ---- gradient buckets: [embedding + sigma_map], one per block, [output layer] -------------------------------
+    def _make_buckets(self):
+        ids = {id(p): i for i, p in enumerate(self.flat.params)}
+        buckets, assigned = [], set()
+        blocks = list(getattr(self.model, "blocks", []))
+
+        def rng(ps):
+            idx = sorted(ids[id(p)] for p in ps if id(p) in ids)
+            if not idx:
+                return None
+            assigned.update(idx)
+            lo = self.flat.offsets[idx[0]]
+            last = idx[-1]
+            hi = self.flat.offsets[last + 1] if last + 1 < len(self.flat.offsets) else self.flat.n
+            return (lo, hi)
+
+        for b, blk in enumerate(blocks):
+            r = rng(list(blk.parameters()))
+            if r:
+                buckets.append(r)
+                if self.overlap:
+                    blk._on_grads_ready = (lambda rr: (lambda: self._launch_allreduce(rr)))(r)
+        self._rest = [i for i in range(len(self.flat.params)) if i not in assigned]
+        return buckets
+
+    def _launch_allreduce(self, r):
+        self._pending.append(dist.all_reduce(self.flat.g[r[0]:r[1]], group=self.pg, async_op=True))
+
+    def broadcast_parameters(self, src=0):
+        dist.broadcast(self.flat.p, src, group=self.pg)
+        self.flat.ema.copy_(self.flat.p)
+        if self.flat.pc is not None:
+            ops.cast(self.flat.p, torch.bfloat16, out=self.flat.pc)
+        self.flat.refresh_compute_weights()
+
+    def current_lr(self, step):
+        return self.lr * min(step / self.warmup, 1.0) if self.warmup and self.warmup > 0 else self.lr
+
+    def train_step(self, batch, t=None, perturbed_batch=None, u=None):
+        """One optimisation step (losses.py:80-115 with accum = 1). Returns the local loss (0-dim device tensor)."""
+        fl = self.flat
+        fl.g.zero_()
+        self.model.train()
+        loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
+        loss.backward()
+        if self.world > 1:
+            if self.overlap:
+                done = {(r[0], r[1]) for r in self._buckets}
+                # whatever is not in a block bucket (embedding, sigma_map, output layer): contiguous leftovers
+                for lo, hi in self._leftover_ranges(done):
+                    self._pending.append(dist.all_reduce(fl.g[lo:hi], group=self.pg, async_op=True))
+                for w in self._pending:
+                    w.wait()
+                self._pending = []
+            else:
+                dist.all_reduce(fl.g, group=self.pg)
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        clip = None
+        if self.grad_clip is not None and self.grad_clip >= 0:
+            ops.sumsq_clip(fl.g, gscale, self.grad_clip, self._ws, self._norm)
+            clip = self._norm[1:]
+        self.ema.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
+        ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, self.current_lr(self.step_count),
+                           self.beta1, self.beta2, self.eps, self.wd, self.step_count, decay)
+        fl.refresh_compute_weights()
+        return loss.detach()
+
+    def _leftover_ranges(self, done):
+        cov = sorted(done)
+        out, pos = [], 0
+        for lo, hi in cov:
+            if lo > pos:
+                out.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.flat.n:
+            out.append((pos, self.flat.n))
+        return out
+
+    def grad_norm(self):
+        """global gradient norm of the last step (after averaging over ranks)."""
+        return float(self._norm[0]) ** 0.5 / self.world
+
+    def reduce_loss(self, loss):
+        """scalar loss all-reduce(AVG) for logging (run_train_ddp_protlig_transf.py:285)."""
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, group=self.pg)
+            loss /= self.world
+        return loss
+
+    # ---- checkpoint in the reference's layout (utils/utils.py:87-95: optimizer / model / ema / step) ------------
+    def state_dict(self):
+        return {"optimizer": {"m": self.flat.m, "v": self.flat.v, "step": self.step_count},
+                "model": self.model.state_dict(), "ema": self.ema.state_dict(), "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd["model"])
+        self.flat.m.copy_(sd["optimizer"]["m"])
+        self.flat.v.copy_(sd["optimizer"]["v"])
+        self.step_count = int(sd["step"])
+        for dst, src in zip(self.flat.ema_params(), sd["ema"]["shadow_params"]):
+            dst.copy_(src)
+        self.ema.num_updates = sd["ema"]["num_updates"]
+        if self.flat.pc is not None:
+            ops.cast(self.flat.p, torch.bfloat16, out=self.flat.pc)
+        self.flat.refresh_compute_weights()
+
+
+def shard_batch(batch, rank, world):
+    """DistributedSampler-style contiguous shard of a global batch (data/process_full_plinder.py:396-398)."""
+    per = batch.shape[0] // world
+    return batch[rank * per:(rank + 1) * per]
+
+
+def sharded_sampling(sampler, model, rank, world, gather=True, **kw):
+    """Batch-sharded sampling: every rank samples its own shard with no communication during the steps; one final
+    all_gather of the int64 indices."""
+    x = sampler(model, **kw)
+    if world == 1 or not gather:
+        return x
+    out = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(out, x)
+    return torch.cat(out, 0)
