@@ -75,14 +75,11 @@ def lib():
     L.sedd_abi_version.restype = ctypes.c_int
     L.sedd_last_error.restype = ctypes.c_char_p
     for name, sig in SIGNATURES.items():
-        if not hasattr(L, name) and os.environ.get("SEDD_DEV_ALLOW_MISSING"):
-            continue  # bring-up only
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = [_T[c] for c in sig]
         fn.restype = ctypes.c_int
-    if hasattr(L, "sedd_ln_bwd_chunks") or not os.environ.get("SEDD_DEV_ALLOW_MISSING"):
-        L.sedd_ln_bwd_chunks.argtypes = [ctypes.c_int64, ctypes.c_int64]
-        L.sedd_ln_bwd_chunks.restype = ctypes.c_int64
+    L.sedd_ln_bwd_chunks.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.sedd_ln_bwd_chunks.restype = ctypes.c_int64
     _lib = L
     return L
 

@@ -236,19 +236,33 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
 }
 
 // ============================================================================================ delta pre-pass
+// 8 lanes per (b, q, h) row, each lane d/8 contiguous elements in 4-element vector loads; xor-shuffle reduce.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
 template <typename T>
 __global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
                                                          float* __restrict__ delta, int B, int H, int Lq, int D,
                                                          int64_t o_bs, int64_t o_ls) {
-    const int64_t total = (int64_t)B * H * Lq;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int qi = (int)(idx % Lq);
-        const int h = (int)((idx / Lq) % H);
+    const int64_t total = (int64_t)B * Lq * H;
+    const int sub = threadIdx.x & 7, per = D / 8;
+    for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * 256) >> 3) {
+        const int h = (int)(idx % H);
+        const int qi = (int)((idx / H) % Lq);
         const int b = (int)(idx / ((int64_t)Lq * H));
-        const int64_t off = b * o_bs + (int64_t)qi * o_ls + (int64_t)h * D;
+        const int64_t off = b * o_bs + (int64_t)qi * o_ls + (int64_t)h * D + sub * per;
         float s = 0.f;
-        for (int d = 0; d < D; ++d) s += to_f32<T>(o[off + d]) * to_f32<T>(dout[off + d]);
-        delta[idx] = s;
+        for (int d = 0; d < per; d += 4) {
+            const float4 x = ld4(o + off + d), y = ld4(dout + off + d);
+            s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (sub == 0) delta[((int64_t)b * H + h) * Lq + qi] = s;
     }
 }
 
@@ -480,10 +494,10 @@ extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const 
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * H * Lq;
     if (dtype == SEDD_BF16)
-        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3(sedd_grid_for(rows, 256, 256 * 16)), dim3(256), 0, st,
+        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3(sedd_grid_for(rows * 8, 256, 256 * 16)), dim3(256), 0, st,
                            (const bf16_t*)o, (const bf16_t*)dout, delta, B, H, Lq, d, o_bs, o_ls);
     else
-        hipLaunchKernelGGL((attn_delta_kernel<float>), dim3(sedd_grid_for(rows, 256, 256 * 16)), dim3(256), 0, st,
+        hipLaunchKernelGGL((attn_delta_kernel<float>), dim3(sedd_grid_for(rows * 8, 256, 256 * 16)), dim3(256), 0, st,
                            (const float*)o, (const float*)dout, delta, B, H, Lq, d, o_bs, o_ls);
     const dim3 gq((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H), gk((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
     DISPATCH_ATTN(dtype, d, {

@@ -157,17 +157,7 @@ class SEDDTrainer:
         self.model.train()
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
         loss.backward()
-        if self.world > 1:
-            if self.overlap:
-                done = {(r[0], r[1]) for r in self._buckets}
-                # whatever is not in a block bucket (embedding, sigma_map, output layer): contiguous leftovers
-                for lo, hi in self._leftover_ranges(done):
-                    self._pending.append(dist.all_reduce(fl.g[lo:hi], group=self.pg, async_op=True))
-                for w in self._pending:
-                    w.wait()
-                self._pending = []
-            else:
-                dist.all_reduce(fl.g, group=self.pg)
+        self._reduce_gradients()
         self.step_count += 1
         gscale = 1.0 / self.world
         clip = None
@@ -180,6 +170,22 @@ class SEDDTrainer:
                            self.beta1, self.beta2, self.eps, self.wd, self.step_count, decay)
         fl.refresh_compute_weights()
         return loss.detach()
+
+    def _reduce_gradients(self):
+        """Finish the gradient all-reduce (SUM; the 1/world averaging is folded into the optimiser kernel's grad_scale):
+        block buckets were launched asynchronously from the backward hooks, the leftovers (embedding, sigma_map, output
+        layer) go now; then wait for everything."""
+        if self.world <= 1:
+            return
+        fl = self.flat
+        if self.overlap:
+            for lo, hi in self._leftover_ranges({(r[0], r[1]) for r in self._buckets}):
+                self._pending.append(dist.all_reduce(fl.g[lo:hi], group=self.pg, async_op=True))
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+        else:
+            dist.all_reduce(fl.g, group=self.pg)
 
     def _leftover_ranges(self, done):
         cov = sorted(done)

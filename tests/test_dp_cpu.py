@@ -1,0 +1,103 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: flat-buffer layout, per-block gradient buckets launched
+from the backward hooks + leftover ranges cover the whole buffer exactly once, parameter broadcast, batch sharding and
+the sharded-sampling all_gather.  The kernels themselves are covered by the -m gpu tests."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    ns = types.SimpleNamespace
+    return ns(tokens=25, graph=ns(type="absorb"),
+              model=ns(hidden_size=64, cond_dim=32, n_heads=2, n_blocks=3, dropout=0.0, scale_by_sigma=True))
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from protein_lig_sedd_amd import graph_lib, noise_lib
+        from protein_lig_sedd_amd.model.transformer import _SEDD
+        from protein_lig_sedd_amd.train import SEDDTrainer, shard_batch, sharded_sampling
+        torch.manual_seed(100 + rank)  # different init per rank: broadcast must make them equal
+        model = _SEDD(_cfg(), compute_dtype=torch.float32)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        tr = SEDDTrainer(model, noise_lib.LogLinearNoise(), graph_lib.Absorbing(25), dict(lr=1e-3), world_size=world)
+        fl = tr.flat
+        # 1. broadcast: rank 0's parameters everywhere, params / grads are views of the flat buffers
+        ref = [torch.empty_like(fl.p) for _ in range(world)]
+        dist.all_gather(ref, fl.p)
+        assert torch.equal(ref[0], ref[1])
+        for i, p in enumerate(fl.params):
+            assert p.data_ptr() == fl.view(fl.p, i).data_ptr() and p.grad.data_ptr() == fl.view(fl.g, i).data_ptr()
+            assert fl.offsets[i] % 64 == 0
+        assert torch.equal(fl.ema, fl.p)
+        # 2. buckets + leftovers tile [0, n) exactly once
+        cover = sorted(tr._buckets + tr._leftover_ranges({(a, b) for a, b in tr._buckets}))
+        pos = 0
+        for lo, hi in cover:
+            assert lo == pos and hi > lo
+            pos = hi
+        assert pos == fl.n and len(tr._buckets) == 3
+        # 3. gradient all-reduce through the backward hooks (async per-block buckets) + leftovers
+        fl.g.copy_(torch.arange(fl.n, dtype=torch.float32) * (rank + 1))
+        for blk in reversed(model.blocks):   # the order backward finishes the blocks in
+            blk._on_grads_ready()
+        tr._reduce_gradients()
+        expect = torch.arange(fl.n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        assert torch.equal(fl.g, expect)
+        assert tr._pending == []
+        # non-overlapped path gives the same
+        tr.overlap = False
+        fl.g.copy_(torch.arange(fl.n, dtype=torch.float32) * (rank + 1))
+        tr._reduce_gradients()
+        assert torch.equal(fl.g, expect)
+        # 4. scalar loss all-reduce(AVG)
+        assert abs(float(tr.reduce_loss(torch.tensor(float(rank)))) - 0.5) < 1e-6
+        # 5. batch sharding + sharded sampling gather
+        batch = torch.arange(8 * 5).view(8, 5)
+        mine = shard_batch(batch, rank, world)
+        assert torch.equal(mine, batch[rank * 4:(rank + 1) * 4])
+        out = sharded_sampling(lambda m, **kw: mine + 0, None, rank, world)
+        assert torch.equal(out, batch)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_dp_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_lr_warmup_and_ema_decay_host_math():
+    sys.path.insert(0, ROOT)
+    from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
+    e = ExponentialMovingAverage([], 0.9999)
+    assert abs(e.current_decay() - 2 / 11) < 1e-12
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    t = SEDDTrainer.__new__(SEDDTrainer)
+    t.lr, t.warmup = 3e-4, 100
+    assert t.current_lr(1) == 3e-4 / 100 and t.current_lr(100) == 3e-4 and t.current_lr(1000) == 3e-4
