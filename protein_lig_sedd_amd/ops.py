@@ -387,7 +387,7 @@ def _attn_strides(t):
     return t.stride(0), t.stride(1)
 
 
-def attn_fwd(q, k, v, key_mask=None):
+def attn_fwd(q, k, v, key_mask=None, out=None):
     """q [B, Lq, H, d], k/v [B, Lk, H, d] (strided views of a packed qkv allowed; k and v share strides).
     key_mask: optional bool/uint8 [B, Lk], True = attend.  -> (o [B, Lq, H, d] contiguous, lse fp32 [B, H, Lq])."""
     B, Lq, H, d = q.shape
@@ -395,7 +395,8 @@ def attn_fwd(q, k, v, key_mask=None):
     qs, ks = _attn_strides(q), _attn_strides(k)
     if _attn_strides(v) != ks:
         raise ValueError("k and v must share strides")
-    o = torch.empty(B, Lq, H, d, dtype=q.dtype, device=q.device)
+    o = torch.empty(B, Lq, H, d, dtype=q.dtype, device=q.device) if out is None else out
+    _attn_strides(o)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     km = None if key_mask is None else _c(key_mask.to(torch.uint8))
     with _Timed("attn_fwd", 4.0 * B * H * Lq * Lk * d):
@@ -411,7 +412,6 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None):
     qs, ks = _attn_strides(q), _attn_strides(k)
     if _attn_strides(dq) != qs or _attn_strides(dk) != ks or _attn_strides(dv) != ks or _attn_strides(v) != ks:
         raise ValueError("gradient views must share the strides of their primal tensors")
-    dout = _c(dout)
     if _attn_strides(dout) != _attn_strides(o):
         raise ValueError("dout must be laid out like o")
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
