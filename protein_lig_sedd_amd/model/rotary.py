@@ -13,9 +13,14 @@ class Rotary(torch.nn.Module):
         self.seq_len_cached = None
         self.cos_cached = None
         self.sin_cached = None
+        self._by_len = {}  # (L, device) -> (cos, sin): both tracks of the dual model keep their tables
 
     def forward(self, x, seq_dim=1):
         seq_len = x.shape[seq_dim]
+        hit = self._by_len.get((seq_len, x.device))
+        if hit is not None:
+            self.seq_len_cached, self.cos_cached, self.sin_cached = seq_len, hit[0], hit[1]
+            return hit
         if seq_len != self.seq_len_cached or self.cos_cached.device != x.device:
             self.seq_len_cached = seq_len
             t = torch.arange(seq_len, device=x.device).type_as(self.inv_freq)
@@ -30,6 +35,7 @@ class Rotary(torch.nn.Module):
             # compact [L, d/2] fp32 halves the kernel reads (what flash-attn's rotary takes, rotary.py:44-45)
             self.cos_cached._sedd_compact = (emb.cos()[:, :half].float().contiguous(),
                                              emb.sin()[:, :half].float().contiguous())
+            self._by_len[(seq_len, x.device)] = (self.cos_cached, self.sin_cached)
         return self.cos_cached, self.sin_cached
 
 

@@ -1,0 +1,133 @@
+"""GPU parity of the dual-track cross-attention model (transformers_protlig_cross drop-in) against the golden vectors
+captured from the reference (G8 cross block, G9 CrossAttentionLayer, G11 full ProteinLigandDiffusionModel incl. the
+as-written batch-axis self-attention, quirk Q1).  fp32 compute, 1e-4 relative."""
+import types
+
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from oracle.weights import seeded_state_dict
+from test_oracle_vs_golden import _block_shapes, cross_shapes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load_sd(module, sd):
+    missing, unexpected = module.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("inv_freq") for k in missing), missing
+
+
+def test_g8_cross_block(golden):
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import DDiTBlock
+    from protein_lig_sedd_amd.model.rotary import Rotary
+    g = golden("g8_ddit_block")
+    t = "cross_"
+    D, H, C, B, L, Lo = g[t + "dims"].tolist()
+    blk = DDiTBlock(D, H, 0.0, C).to(DEV)
+    load_sd(blk, seeded_state_dict(_block_shapes(D, C, cross=True), seed=9, std=0.05))
+    rot = Rotary(D // H).to(DEV)
+    x = g[t + "x"].to(DEV).requires_grad_(True)
+    c = g[t + "c"].to(DEV).requires_grad_(True)
+    other = g[t + "other"].to(DEV).requires_grad_(True)
+    with torch.no_grad():
+        assert_close(blk(x, rot(x), c), g[t + "y_noother"], 1e-4, 5e-5, "no other")
+        assert_close(blk(x, rot(x), c, other, g[t + "mask"].to(DEV)), g[t + "y_masked"], 1e-4, 5e-5, "masked")
+    y = blk(x, rot(x), c, other)
+    assert_close(y, g[t + "y"], 1e-4, 5e-5, "y")
+    (y * g[t + "w"].to(DEV)).sum().backward()
+    assert_close(x.grad, g[t + "dx"], 1e-4, 5e-5, "dx")
+    assert_close(other.grad, g[t + "dother"], 1e-4, 5e-5, "dother")
+    assert_close(c.grad, g[t + "dc"], 1e-4, 4e-4, "dc")
+    for k, p in blk.named_parameters():
+        ref = g[t + "grad." + k]
+        assert rel_err(p.grad, ref) < 2e-4, k
+        assert_close(p.grad, ref, 1e-4, 4e-4, k)
+
+
+def test_g9_cross_attention_layer(golden):
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import CrossAttentionLayer
+    g = golden("g9_cross_attention")
+    D, H, B, Lq, Lk = g["dims"].tolist()
+    shapes = {"cross_attn.in_proj_weight": (3 * D, D), "cross_attn.in_proj_bias": (3 * D,),
+              "cross_attn.out_proj.weight": (D, D), "cross_attn.out_proj.bias": (D,),
+              "norm.weight": (D,), "norm.bias": (D,)}
+    lyr = CrossAttentionLayer(D, H, 0.0).to(DEV).eval()
+    load_sd(lyr, seeded_state_dict(shapes, seed=10, std=0.08))
+    with torch.no_grad():
+        assert_close(lyr(g["x"].to(DEV), g["ctx"].to(DEV)), g["y"], 1e-4, 1e-5)
+        assert_close(lyr(g["x"].to(DEV), g["ctx"].to(DEV), context_mask=g["mask"].to(DEV)), g["y_masked"], 1e-4, 1e-5)
+
+
+def _cfg(D, H, C, nb):
+    ns = types.SimpleNamespace
+    return ns(graph=ns(type="absorb"), model=ns(hidden_size=D, cond_dim=C, n_heads=H, n_blocks=nb, dropout=0.0,
+                                                scale_by_sigma=True))
+
+
+def test_g11_cross_model(golden):
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd import graph_lib
+    g = golden("g11_cross_model")
+    D, H, C, nb = g["cfg"].tolist()
+    model = ProteinLigandDiffusionModel(_cfg(D, C=C, H=H, nb=nb)).to(DEV)
+    load_sd(model, seeded_state_dict(cross_shapes(D, C, nb), seed=11, std=0.05))
+    pt, lt, p0, l0 = (g[k].to(DEV) for k in ("pt", "lt", "p0", "l0"))
+    sigma, dsigma = g["sigma"].to(DEV), g["dsigma"].to(DEV)
+    model.train()
+    lp, ll = model(protein_indices=pt, ligand_indices=lt, timesteps=sigma, mode="joint")
+    assert rel_err(lp, g["joint_prot_logits"]) < 1e-4 and rel_err(ll, g["joint_lig_logits"]) < 1e-4
+    assert_close(lp, g["joint_prot_logits"], 1e-4, 2e-4)
+    assert_close(ll, g["joint_lig_logits"], 1e-4, 2e-4)
+    gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+    se_p = gp.score_entropy(lp, sigma[:, None], pt, p0)
+    se_l = gl.score_entropy(ll, sigma[:, None], lt, l0)
+    # the trainer's as-written joint loss (quirk Q3: mean first, then x dsigma; run_train_protlig_cross_att.py:289-294)
+    loss_q3 = (dsigma[:, None] * ((se_p.mean() + se_l.mean()) / 2)).mean()
+    assert_close(loss_q3, g["joint_loss_q3"], 1e-4, 0)
+    assert_close(((dsigma[:, None] * se_p).mean() + (dsigma[:, None] * se_l).mean()) / 2, g["joint_loss_persample"], 1e-4, 0)
+    loss_q3.backward()
+    for k, p in model.named_parameters():
+        ref = g["joint_grad." + k]
+        assert_close(p.grad, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-7, k)
+    model.eval()
+    with torch.no_grad():
+        assert_close(model(protein_indices=pt, timesteps=sigma, mode="protein_only"), g["prot_only_logits"], 1e-4, 2e-4)
+        assert_close(model(ligand_indices=lt, timesteps=sigma, mode="ligand_only"), g["lig_only_logits"], 1e-4, 2e-4)
+        assert_close(model(protein_indices=p0, ligand_indices=lt, timesteps=sigma, mode="ligand_given_protein"),
+                     g["lig_given_prot_logits"], 1e-4, 2e-4)
+        assert_close(model(protein_indices=pt, ligand_indices=l0, timesteps=sigma, mode="protein_given_ligand"),
+                     g["prot_given_lig_logits"], 1e-4, 2e-4)
+    with pytest.raises(ValueError):
+        model(protein_indices=pt, timesteps=sigma, mode="nope")
+
+
+def test_cross_model_sampler_and_bf16():
+    """Euler pc_sampler through the dual-track model (the reference's keyword call, sampling.py:64-76) and the bf16
+    opt-in vs the fp32 path (2e-2)."""
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd import graph_lib, noise_lib, sampling
+    torch.manual_seed(0)
+    D, H, C, nb = 64, 2, 32, 2
+    sd = seeded_state_dict(cross_shapes(D, C, nb), seed=4, std=0.05)
+    m32 = ProteinLigandDiffusionModel(_cfg(D, H, C, nb)).to(DEV).eval()
+    m16 = ProteinLigandDiffusionModel(_cfg(D, H, C, nb), compute_dtype=torch.bfloat16).to(DEV).eval()
+    load_sd(m32, sd)
+    load_sd(m16, sd)
+    B, Lp, Ll = 3, 24, 16
+    prot = torch.randint(0, 36, (B, Lp), device=DEV)
+    lig = torch.randint(0, 2364, (B, Ll), device=DEV)
+    sigma = torch.rand(B, device=DEV) + 0.2
+    with torch.no_grad():
+        a32 = m32(protein_indices=prot, ligand_indices=lig, timesteps=sigma, mode="joint")
+        a16 = m16(protein_indices=prot, ligand_indices=lig, timesteps=sigma, mode="joint")
+    assert rel_err(a16[0].float(), a32[0]) < 2e-2 and rel_err(a16[1].float(), a32[1]) < 2e-2
+    noise = noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    samp = sampling.get_pc_sampler(graph_lib.Absorbing(2364), noise, (B, Ll), "euler", 4, device=DEV)
+    out = samp(m32, task="ligand_given_protein", prot_indices=prot)
+    assert out.shape == (B, Ll) and int(((out < 0) | (out >= 2364)).sum()) == 0
+    samp = sampling.get_pc_sampler(graph_lib.Absorbing(36), noise, (B, Lp), "analytic", 4, device=DEV)
+    out = samp(m32, task="protein_only")
+    assert out.shape == (B, Lp) and int(((out < 0) | (out >= 36)).sum()) == 0
