@@ -603,22 +603,70 @@ extern "C" int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* 
 
 // ========================================================================================= logits epilogue
 // transformer.py:313-322
-template <typename T>
+// A thread owns one 16-byte chunk of the flat [M*V] array (VEC) or one element (!VEC: unaligned base); the
+// (row, column, batch) coordinates are divided out once per chunk and then advanced incrementally, so the per-element
+// cost is a compare/subtract and the traffic one vector load + one vector store.
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(TPB) logits_epilogue_kernel(T* __restrict__ x, const float* __restrict__ sigma,
                                                               const int64_t* __restrict__ idx, int scale_by_sigma,
                                                               int64_t M, int64_t L, int V) {
+    constexpr int EPT = VEC ? 16 / (int)sizeof(T) : 1;
     const float lv = logf((float)(V - 1));
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < M * V; i += (int64_t)gridDim.x * TPB) {
-        const int64_t row = i / V;
-        const int j = (int)(i % V);
-        float v = to_f32<T>(x[i]);
-        if (scale_by_sigma) {
-            const float el = to_f32<T>(from_f32<T>(logf(esigm1f(sigma[row / L]))));  // .log().to(x.dtype)
-            v = to_f32<T>(from_f32<T>(v - el));
-            v = v - lv;
+    const int64_t total = M * V;
+    const int64_t nchunks = (total + EPT - 1) / EPT;
+    const bool small = total < ((int64_t)1 << 31);
+    for (int64_t c = (int64_t)blockIdx.x * TPB + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * TPB) {
+        const int64_t i0 = c * EPT;
+        int64_t row, b;
+        if (small) {
+            row = (uint32_t)i0 / (uint32_t)V;
+            b = (uint32_t)row / (uint32_t)L;
+        } else {
+            row = i0 / V;
+            b = row / L;
         }
-        if (j == idx[row]) v = 0.f;
-        x[i] = from_f32<T>(v);
+        int j = (int)(i0 - row * V);
+        int64_t rl = row - b * L;
+        float el = scale_by_sigma ? to_f32<T>(from_f32<T>(logf(esigm1f(sigma[b])))) : 0.f;  // .log().to(x.dtype)
+        int64_t tgt = idx[row];
+        T buf[EPT];
+        const bool full = i0 + EPT <= total;
+        if (VEC && full) {
+            *reinterpret_cast<uint4*>(buf) = *reinterpret_cast<const uint4*>(x + i0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (i0 + k < total) buf[k] = x[i0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            float v = to_f32<T>(buf[k]);
+            if (scale_by_sigma) {
+                v = to_f32<T>(from_f32<T>(v - el));
+                v = v - lv;
+            }
+            if (j == tgt) v = 0.f;
+            buf[k] = from_f32<T>(v);
+            if (k + 1 < EPT && ++j == V) {  // step to the next row (and batch element) inside the chunk
+                j = 0;
+                ++row;
+                if (row < M) {
+                    tgt = idx[row];
+                    if (++rl == L) {
+                        rl = 0;
+                        ++b;
+                        if (scale_by_sigma) el = to_f32<T>(from_f32<T>(logf(esigm1f(sigma[b]))));
+                    }
+                }
+            }
+        }
+        if (VEC && full) {
+            *reinterpret_cast<uint4*>(x + i0) = *reinterpret_cast<const uint4*>(buf);
+        } else {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (i0 + k < total) x[i0 + k] = buf[k];
+        }
     }
 }
 extern "C" int sedd_logits_epilogue(void* logits, int dtype, const float* sigma, const int64_t* idx,
@@ -627,9 +675,16 @@ extern "C" int sedd_logits_epilogue(void* logits, int dtype, const float* sigma,
     SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "logits_epilogue: bad sizes");
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(logits && idx && (!scale_by_sigma || sigma), "logits_epilogue: null pointer");
-    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((logits_epilogue_kernel<T>), dim3(sedd_grid_for(M * V, TPB, 256 * 16)),
-                                             dim3(TPB), 0, (hipStream_t)stream, (T*)logits, sigma, idx,
-                                             scale_by_sigma, M, L, V));
+    const int ept = dtype == SEDD_F32 ? 4 : 8;
+    if (((uintptr_t)logits & 15) == 0) {
+        DISPATCH_DT(dtype, T, hipLaunchKernelGGL((logits_epilogue_kernel<T, true>),
+                                                 dim3(sedd_grid_for((M * V + ept - 1) / ept, TPB, 256 * 16)), dim3(TPB), 0,
+                                                 (hipStream_t)stream, (T*)logits, sigma, idx, scale_by_sigma, M, L, V));
+    } else {
+        DISPATCH_DT(dtype, T, hipLaunchKernelGGL((logits_epilogue_kernel<T, false>),
+                                                 dim3(sedd_grid_for(M * V, TPB, 256 * 16)), dim3(TPB), 0,
+                                                 (hipStream_t)stream, (T*)logits, sigma, idx, scale_by_sigma, M, L, V));
+    }
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

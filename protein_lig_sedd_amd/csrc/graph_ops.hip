@@ -30,6 +30,103 @@ __device__ __forceinline__ float gumbel_ratio(float p, float u) {
     return p / (1e-10f - logf(u + 1e-10f));
 }
 
+
+// logf for arguments that are never subnormal (u + 1e-10 with u >= 0): the library's algorithm — v_log_f32 followed by a
+// compensated multiplication by ln 2 — without its subnormal pre-scaling, so the bits equal logf's on that domain.
+__device__ __forceinline__ float logf_normal(float x) {
+    const float r = __builtin_amdgcn_logf(x);
+    const float hi = r * 0x1.62e42ep-1f;
+    float lo = fmaf(r, 0x1.62e42ep-1f, -hi);
+    lo = fmaf(r, 0x1.efa39ep-25f, lo);
+    return fabsf(r) < INFINITY ? hi + lo : r;
+}
+__device__ __forceinline__ float gumbel_ratio_fast(float p, float u) {
+    return p / (1e-10f - logf_normal(u + 1e-10f));
+}
+// arg-max over a row scanned in increasing index order, torch semantics (first maximum; NaN is the maximum)
+struct ArgmaxScan {
+    float bv;
+    int bi, ni;
+    __device__ __forceinline__ void first(float v) { bv = v; bi = 0; ni = v != v ? 0 : 0x7fffffff; }
+    __device__ __forceinline__ void push(float v, int j) {
+        if (v > bv) { bv = v; bi = j; }
+        if (v != v && ni == 0x7fffffff) ni = j;
+    }
+    __device__ __forceinline__ int result() const { return ni != 0x7fffffff ? ni : bi; }
+};
+// Rows that need the full computation are compacted to the front of the block (wave ballot + one LDS atomic per wave)
+// so that for an absorbing graph whole waves retire when most rows of a tile are unmasked fixed points.
+__device__ __forceinline__ void rows_compact(bool active, int r, int* s_cnt, unsigned short* s_list) {
+    const unsigned long long mask = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(s_cnt, __popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (active) s_list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)r;
+}
+
+// ===================================================================== small-vocab "row per lane" machinery
+// For V <= 64 a G-lane group per row wastes most of its instructions on cross-lane shuffles, so the V <= 64 paths of
+// score_entropy / gumbel_argmax / predictor_step use a second layout: a block stages ROWS consecutive rows — one
+// contiguous, 16-byte aligned byte range of each [M, V] array — into LDS with 16-byte LDS-DMA loads (fully coalesced,
+// no VGPR round trip), then every lane owns ONE row and walks its V entries out of LDS with compile-time unrolled
+// loops (row stride V*esize bytes: conflict-free or 2-way for the vocabularies in use; strides that are a multiple of
+// 32 bytes fall back to the group kernels).  Row sums are evaluated in the same association order as the group
+// kernels' xor-shuffle tree, so both layouts return identical bits.
+template <int VP> struct RowsCfg { static constexpr int ROWS = VP == 64 ? 128 : 256; };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void rows_stage_in(const unsigned char* __restrict__ g, unsigned char* s, int nbytes,
+                                              int nthreads) {
+    const int nch = nbytes >> 4;
+    const int lane = threadIdx.x & 63;
+    for (int c0 = threadIdx.x - lane; c0 < nch; c0 += nthreads) {  // wave-uniform trip count and LDS base
+        if (c0 + lane < nch)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + (int64_t)(c0 + lane) * 16), (lptr_t)(s + c0 * 16), 16, 0, 0);
+    }
+    const int done = nch << 4;
+    if ((int)threadIdx.x < nbytes - done) s[done + threadIdx.x] = g[done + threadIdx.x];
+}
+__device__ __forceinline__ void rows_stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ void rows_stage_out(unsigned char* __restrict__ g, const unsigned char* s, int nbytes,
+                                               int nthreads) {
+    const int nch = nbytes >> 4;
+    for (int c = threadIdx.x; c < nch; c += nthreads) ((uint4*)g)[c] = ((const uint4*)s)[c];
+    const int done = nch << 4;
+    if ((int)threadIdx.x < nbytes - done) g[done + threadIdx.x] = s[done + threadIdx.x];
+}
+// sum of v[0..VP) in the association order of group_sum<VP> (xor-shuffle tree, lane j holding v[j]); destroys v
+template <int VP> __device__ __forceinline__ float tree_sum(float (&v)[VP]) {
+#pragma unroll
+    for (int off = VP / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < off; ++i) v[i] = v[i] + v[i + off];
+    }
+    return v[0];
+}
+// nu = number of fp32 noise columns staged beside the esize-byte score columns (0: none)
+static inline bool rows_path_ok(int V, int esize, int nu, const void* a, const void* b, const void* c) {
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    const int rows = V > 32 ? 128 : 256;
+    const size_t lds = ((size_t)rows * V * esize + 15) / 16 * 16 + (size_t)rows * nu * 4;
+    return V <= 64 && (V * esize) % 32 != 0 && (nu == 0 || (nu * 4) % 32 != 0) && (al & 15) == 0 && lds <= 62 * 1024;
+}
+__host__ __device__ __host__ __device__ static inline size_t rows_lds(int rows, int rowbytes) { return ((size_t)rows * rowbytes + 15) & ~(size_t)15; }
+#define SEDD_DISPATCH_VP(V, ...)                          \
+    do {                                                  \
+        switch (sedd_group_for(V)) {                      \
+            case 8:  { constexpr int VP = 8;  __VA_ARGS__; } break; \
+            case 16: { constexpr int VP = 16; __VA_ARGS__; } break; \
+            case 32: { constexpr int VP = 32; __VA_ARGS__; } break; \
+            default: { constexpr int VP = 64; __VA_ARGS__; } break; \
+        }                                                 \
+    } while (0)
+
 // ------------------------------------------------------------------------------------- sample_transition
 // graph_lib.py:258-262 (absorbing), :156-160 (uniform)
 __global__ void __launch_bounds__(TPB) sample_transition_kernel(int graph, const int64_t* __restrict__ x0,
@@ -141,10 +238,143 @@ __global__ void __launch_bounds__(TPB) score_entropy_kernel(int graph, const T* 
     }
 }
 
+// row-per-lane variant (V <= 64), same arithmetic; the gradient tile is built in place over the staged scores and
+// leaves with 16-byte stores
+template <typename T, int VP>
+__global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
+    score_entropy_rows_kernel(int graph, const T* __restrict__ score, const float* __restrict__ sigma,
+                              const int64_t* __restrict__ x, const int64_t* __restrict__ x0, float* __restrict__ out,
+                              T* __restrict__ dscore, const float* __restrict__ gw, const float* __restrict__ gout,
+                              int64_t M, int64_t L, int V) {
+    constexpr int ROWS = RowsCfg<VP>::ROWS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_cnt;
+    __shared__ unsigned short s_list[ROWS];
+    __shared__ int s_x[ROWS];
+    __shared__ int64_t s_x0[ROWS];
+    __shared__ float s_sig[ROWS], s_w[ROWS];
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int nrows = (int)(M - row0 < ROWS ? M - row0 : ROWS);
+    const int nbytes = nrows * V * (int)sizeof(T);
+    if (threadIdx.x == 0) s_cnt = 0;
+    rows_stage_in((const unsigned char*)(score + row0 * V), smem, nbytes, ROWS);
+    int r = threadIdx.x;
+    int64_t xr = 0, x0r = 0;
+    float sig_r = 0.f, w_r = 0.f;
+    if (r < nrows) {  // per-row scalars are fetched under the staging latency and handed over through LDS
+        xr = x[row0 + r];
+        x0r = x0[row0 + r];
+        sig_r = sigma[(row0 + r) / L];
+        if (dscore) w_r = gout ? gout[row0 + r] : gw[(row0 + r) / L];
+    }
+    rows_stage_wait();
+    bool active = false;
+    if (r < nrows) {
+        if (graph == SEDD_ABSORB && xr != V - 1) {  // unmasked token: zero loss, zero gradient
+            if (out) out[row0 + r] = 0.f;
+            if (dscore) {
+                T* srow = (T*)smem + r * V;
+#pragma unroll
+                for (int j = 0; j < VP; ++j)
+                    if (j < V) srow[j] = from_f32<T>(0.f);
+            }
+        } else {
+            active = true;
+            s_x[r] = (int)xr;
+            s_x0[r] = x0r;
+            s_sig[r] = sig_r;
+            s_w[r] = w_r;
+        }
+    }
+    rows_compact(active, r, &s_cnt, s_list);
+    __syncthreads();
+    const int slot = (threadIdx.x + ROWS - 64 * (blockIdx.x % (ROWS / 64))) % ROWS;  // see predictor_step_rows_kernel
+    if (slot < s_cnt) {
+        r = s_list[slot];
+        const int64_t row = row0 + r;
+        const int xi = s_x[r];
+        const float es = esigm1f(s_sig[r]);
+        T* srow = (T*)smem + r * V;
+        const float w = s_w[r];
+        if (graph == SEDD_ABSORB) {
+            int64_t o = s_x0[r];
+            o = o < 0 ? 0 : (o > V - 1 ? V - 1 : o);
+            const float ratio = 1.0f / es;
+            float t[VP];
+            float so = 0.f;
+#pragma unroll
+            for (int j = 0; j < VP; ++j) {
+                t[j] = 0.f;
+                if (j < V) {
+                    const float s = to_f32<T>(srow[j]);
+                    const float e = j < V - 1 ? expf(s) : 0.f;
+                    t[j] = e;
+                    if (j == o) so = s;
+                    if (dscore) srow[j] = from_f32<T>(w * (e - (j == o ? ratio : 0.f)));
+                }
+            }
+            const float pos = tree_sum<VP>(t);
+            if (out) out[row] = pos - ratio * so + ratio * (logf(ratio) - 1.0f);
+        } else {
+            const float Vf = (float)V;
+            const int64_t o = s_x0[r];
+            const float ratio = 1.0f - Vf / (es + Vf);
+            const bool same = xi == o;
+            float ts[VP], te[VP];
+            float sx = 0.f, so = 0.f;
+#pragma unroll
+            for (int j = 0; j < VP; ++j) {
+                ts[j] = 0.f;
+                te[j] = 0.f;
+                if (j < V) {
+                    const float s = to_f32<T>(srow[j]);
+                    const float e = expf(s);
+                    ts[j] = s;
+                    te[j] = e;
+                    if (j == xi) sx = s;
+                    if (j == o) so = s;
+                    if (dscore) {
+                        // d pos = (e^s_j - [j==x] e^s_x)/V ; d neg0 = (1 - [j==x])/V
+                        const float notx = j == xi ? 0.f : 1.f;
+                        const float dpos = notx * e / Vf;
+                        const float dneg0 = notx / Vf;
+                        const float dneg = same ? ratio * dneg0 : (j == o ? 1.0f / es : 0.f) + dneg0;
+                        srow[j] = from_f32<T>(w * (dpos - dneg));
+                    }
+                }
+            }
+            const float ssum = tree_sum<VP>(ts);
+            const float esum = tree_sum<VP>(te);
+            if (out) {
+                float neg = ssum / Vf - sx / Vf;
+                neg = same ? ratio * neg : so / es + neg;
+                const float lr = logf(ratio);
+                const float cst = same ? (Vf - 1.0f) / Vf * ratio * (lr - 1.0f)
+                                       : ((-lr - 1.0f) / ratio - (Vf - 2.0f)) / Vf;
+                const float pos = esum / Vf - expf(sx) / Vf;
+                out[row] = pos - neg + cst;
+            }
+        }
+    }
+    if (dscore) {
+        __syncthreads();
+        rows_stage_out((unsigned char*)(dscore + row0 * V), smem, nbytes, ROWS);
+    }
+}
+
 template <typename T>
 static int launch_score_entropy(int graph, const void* score, const float* sigma, const int64_t* x,
                                 const int64_t* x0, float* out, void* dscore, const float* gw, const float* gout,
                                 int64_t M, int64_t L, int V, hipStream_t st) {
+    if (rows_path_ok(V, (int)sizeof(T), 0, score, dscore, nullptr)) {
+        SEDD_DISPATCH_VP(V, hipLaunchKernelGGL((score_entropy_rows_kernel<T, VP>),
+                                               dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),
+                                               dim3(RowsCfg<VP>::ROWS), rows_lds(RowsCfg<VP>::ROWS, V * (int)sizeof(T)),
+                                               st, graph, (const T*)score, sigma, x, x0, out, (T*)dscore, gw, gout, M,
+                                               L, V));
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((score_entropy_kernel<T, G>), dim3(sedd_grid_for(M, TPB / G)),
                                               dim3(TPB), 0, st, graph, (const T*)score, sigma, x, x0, out,
                                               (T*)dscore, gw, gout, M, L, V));
@@ -210,6 +440,34 @@ __global__ void __launch_bounds__(TPB) gumbel_argmax_kernel(const T* __restrict_
     }
 }
 
+template <typename T, int VP>
+__global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
+    gumbel_argmax_rows_kernel(const T* __restrict__ p, const float* __restrict__ u, int64_t* __restrict__ out,
+                              int64_t M, int V) {
+    constexpr int ROWS = RowsCfg<VP>::ROWS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int nrows = (int)(M - row0 < ROWS ? M - row0 : ROWS);
+    unsigned char* s_u = smem + rows_lds(ROWS, V * (int)sizeof(T));
+    rows_stage_in((const unsigned char*)(p + row0 * V), smem, nrows * V * (int)sizeof(T), ROWS);
+    rows_stage_in((const unsigned char*)(u + row0 * V), s_u, nrows * V * 4, ROWS);
+    rows_stage_wait();
+    const int r = threadIdx.x;
+    if (r >= nrows) return;
+    const T* prow = (const T*)smem + r * V;
+    const float* urow = (const float*)s_u + r * V;
+    ArgmaxScan am;
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        if (j < V) {
+            const float v = gumbel_ratio_fast(to_f32<T>(prow[j]), urow[j]);
+            if (j == 0) am.first(v);
+            else am.push(v, j);
+        }
+    }
+    out[row0 + r] = am.result();
+}
+
 extern "C" int sedd_gumbel_argmax(const void* p, int dtype, const float* u, int64_t* out, int64_t M, int V,
                                   sedd_stream_t stream) {
     SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "gumbel_argmax: unknown dtype %d", dtype);
@@ -217,6 +475,24 @@ extern "C" int sedd_gumbel_argmax(const void* p, int dtype, const float* u, int6
     SEDD_CHECK_ARG(M >= 0 && V > 0, "gumbel_argmax: bad sizes M=%ld V=%d", (long)M, V);
     if (M == 0) return SEDD_OK;
     hipStream_t st = (hipStream_t)stream;
+    const int esz = dtype == SEDD_F32 ? 4 : 2;
+    if (rows_path_ok(V, esz, V, p, u, nullptr)) {
+        if (dtype == SEDD_F32) {
+            SEDD_DISPATCH_VP(V, hipLaunchKernelGGL((gumbel_argmax_rows_kernel<float, VP>),
+                                                   dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),
+                                                   dim3(RowsCfg<VP>::ROWS),
+                                                   rows_lds(RowsCfg<VP>::ROWS, V * 4) + rows_lds(RowsCfg<VP>::ROWS, V * 4),
+                                                   st, (const float*)p, u, out, M, V));
+        } else {
+            SEDD_DISPATCH_VP(V, hipLaunchKernelGGL((gumbel_argmax_rows_kernel<bf16_t, VP>),
+                                                   dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),
+                                                   dim3(RowsCfg<VP>::ROWS),
+                                                   rows_lds(RowsCfg<VP>::ROWS, V * 2) + rows_lds(RowsCfg<VP>::ROWS, V * 4),
+                                                   st, (const bf16_t*)p, u, out, M, V));
+        }
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     if (dtype == SEDD_F32) {
         SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((gumbel_argmax_kernel<float, G>),
                                                   dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st,
@@ -316,6 +592,118 @@ __global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step
     }
 }
 
+// (A persistent, double-buffered variant of this kernel measured slower: the arithmetic — exp, log and an IEEE
+// division per vocabulary entry — needs the occupancy that one small tile per block gives.)
+template <typename T, int VP, int graph, int step>
+__global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
+    predictor_step_rows_kernel(const T* __restrict__ ls, const int64_t* __restrict__ x,
+                               const float* __restrict__ coef, const float* __restrict__ u,
+                               int64_t* __restrict__ xnew, int64_t M, int64_t L, int V) {
+    constexpr int ROWS = RowsCfg<VP>::ROWS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_cnt;
+    __shared__ unsigned short s_list[ROWS];
+    __shared__ int s_x[ROWS];
+    __shared__ float s_cf[ROWS];
+    const int m = V - 1;
+    const int Vu = (graph == SEDD_ABSORB && step == SEDD_STEP_DENOISE) ? V - 1 : V;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int nrows = (int)(M - row0 < ROWS ? M - row0 : ROWS);
+    unsigned char* s_u = smem + rows_lds(ROWS, V * (int)sizeof(T));
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    rows_stage_in((const unsigned char*)(ls + row0 * V), smem, nrows * V * (int)sizeof(T), ROWS);
+    rows_stage_in((const unsigned char*)(u + row0 * Vu), s_u, nrows * Vu * 4, ROWS);
+    const int64_t xi64 = tid < nrows ? x[row0 + tid] : 0;
+    const float cf_own = tid < nrows ? coef[(row0 + tid) / L] : 0.f;  // fetched under the staging latency
+    rows_stage_wait();
+    bool active = false;
+    if (tid < nrows) {
+        if (graph == SEDD_ABSORB && (int)xi64 != m) {
+            int64_t res = xi64;
+            if (step != SEDD_STEP_EULER) {
+                // p_x = (s_x e^{ds}) * e^{-ds}; every other entry is (+-)0, so x wins unless p_x underflowed to 0
+                const float cf = cf_own;
+                const float pi = (expf(to_f32<T>(((const T*)smem)[tid * V + (int)xi64])) * expf(cf)) * expf(-cf);
+                res = (pi > 0.f || pi != pi) ? xi64 : 0;
+            }
+            xnew[row0 + tid] = res;
+        } else {
+            active = true;
+            s_x[tid] = (int)xi64;
+            s_cf[tid] = cf_own;
+        }
+    }
+    rows_compact(active, tid, &s_cnt, s_list);
+    __syncthreads();
+    // surviving rows go to a block-dependent rotation of the waves, so retired waves spread over all SIMDs
+    const int slot = (tid + ROWS - 64 * (blockIdx.x % (ROWS / 64))) % ROWS;
+    if (slot >= s_cnt) return;
+    const int r = s_list[slot];
+    const int64_t row = row0 + r;
+    const int xi = s_x[r];
+    const float cf = s_cf[r];
+    const T* lrow = (const T*)smem + r * V;
+    const float* urow = (const float*)s_u + r * Vu;
+    float e[VP], t[VP];
+    const bool euler = step == SEDD_STEP_EULER;
+    const float invV = 1.0f / (float)V;
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        e[j] = 0.f;
+        t[j] = 0.f;
+        if (j < V) {
+            const float s = expf(to_f32<T>(lrow[j]));
+            e[j] = s;
+            const bool inc = euler ? j != xi : true;  // reverse_rate zeroes the diagonal before summing
+            if (graph == SEDD_UNIFORM && euler) t[j] = inc ? invV * s : 0.f;
+            else t[j] = inc ? s : 0.f;
+        }
+    }
+    const float ssum = tree_sum<VP>(t);
+    float e_p = 0.f, e_n = 0.f, one_m_en = 0.f, extra = 0.f, a_u = 0.f, tval = 0.f, tdiag = 0.f;
+    if (!euler) {
+        e_p = expf(cf);
+        e_n = expf(-cf);
+        one_m_en = 1.0f - e_n;
+        if (graph == SEDD_ABSORB) {
+            extra = (1.0f - e_p) * ssum;
+        } else {
+            a_u = (e_n - 1.0f) / ((float)V * e_n);
+            tval = (1.0f * one_m_en) / (float)V;
+#pragma unroll
+            for (int j = 0; j < VP; ++j) t[j] = (j < V && j != xi) ? tval : 0.f;
+            tdiag = 1.0f - tree_sum<VP>(t);
+        }
+    }
+    ArgmaxScan am;
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        if (j < Vu) {
+            const float s = e[j];
+            float p;
+            if (euler) {
+                float rj;
+                if (graph == SEDD_ABSORB) rj = j == xi ? -ssum : s;  // masked row: transp_rate = 1 off the diagonal
+                else rj = j == xi ? -ssum : invV * s;
+                p = (j == xi ? 1.0f : 0.f) + cf * rj;
+            } else if (graph == SEDD_ABSORB) {
+                float stag = s * e_p;
+                if (j == m) stag += extra;
+                const float tr = j == m ? e_n + one_m_en : one_m_en;
+                p = stag * tr;
+            } else {
+                const float stag = a_u * ssum + s / e_n;
+                p = stag * (j == xi ? tdiag : tval);
+            }
+            const float v = gumbel_ratio_fast(p, urow[j]);
+            if (j == 0) am.first(v);
+            else am.push(v, j);
+        }
+    }
+    xnew[row] = am.result();
+}
+
 extern "C" int sedd_predictor_step(int graph, int step, const void* logscore, int dtype, const int64_t* x,
                                    const float* coef, const float* u, int64_t* xnew, int64_t M, int64_t L, int V,
                                    sedd_stream_t stream) {
@@ -327,6 +715,34 @@ extern "C" int sedd_predictor_step(int graph, int step, const void* logscore, in
                    (long)L, V);
     if (M == 0) return SEDD_OK;
     hipStream_t st = (hipStream_t)stream;
+    const int esz = dtype == SEDD_F32 ? 4 : 2;
+    const int Vu = (graph == SEDD_ABSORB && step == SEDD_STEP_DENOISE) ? V - 1 : V;
+    if (rows_path_ok(V, esz, Vu, logscore, u, nullptr)) {
+#define PRED_ROWS(T, GR, ST)                                                                                          \
+    SEDD_DISPATCH_VP(V, hipLaunchKernelGGL((predictor_step_rows_kernel<T, VP, GR, ST>),                               \
+                                           dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),         \
+                                           dim3(RowsCfg<VP>::ROWS),                                                   \
+                                           rows_lds(RowsCfg<VP>::ROWS, V * (int)sizeof(T)) +                          \
+                                               rows_lds(RowsCfg<VP>::ROWS, Vu * 4),                                   \
+                                           st, (const T*)logscore, x, coef, u, xnew, M, L, V))
+#define PRED_ROWS_ST(T, GR)                                                    \
+    do {                                                                       \
+        if (step == SEDD_STEP_EULER) PRED_ROWS(T, GR, SEDD_STEP_EULER);        \
+        else if (step == SEDD_STEP_ANALYTIC) PRED_ROWS(T, GR, SEDD_STEP_ANALYTIC); \
+        else PRED_ROWS(T, GR, SEDD_STEP_DENOISE);                              \
+    } while (0)
+        if (dtype == SEDD_F32) {
+            if (graph == SEDD_ABSORB) PRED_ROWS_ST(float, SEDD_ABSORB);
+            else PRED_ROWS_ST(float, SEDD_UNIFORM);
+        } else {
+            if (graph == SEDD_ABSORB) PRED_ROWS_ST(bf16_t, SEDD_ABSORB);
+            else PRED_ROWS_ST(bf16_t, SEDD_UNIFORM);
+        }
+#undef PRED_ROWS_ST
+#undef PRED_ROWS
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     if (dtype == SEDD_F32) {
         SEDD_DISPATCH_GROUP(V, hipLaunchKernelGGL((predictor_step_kernel<float, G>),
                                                   dim3(sedd_grid_for(M, TPB / G)), dim3(TPB), 0, st, graph, step,

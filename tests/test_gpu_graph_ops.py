@@ -181,6 +181,45 @@ def test_predictor_steps_vs_oracle(V, dtype):
             assert int((out == V - 1).sum()) == 0  # the denoiser never leaves a mask
 
 
+def _misaligned(t):
+    """same values at an address that is not 16-byte aligned (routes the C ABI to the lane-group kernels)."""
+    buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
+    v = buf[1:1 + t.numel()].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+    return v
+
+
+@pytest.mark.parametrize("V", [9, 26, 37, 50])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_per_lane_layout_matches_group_layout(V, dtype):
+    """V <= 64 has two kernel layouts (LDS-staged row-per-lane for aligned buffers, lane-group otherwise): same bits
+    for loss, gradient and sampled ids; sizes cover several tiles, a ragged last tile and a <16-byte tail."""
+    from protein_lig_sedd_amd import ops, _lib as L
+    GL = _graphs()
+    torch.manual_seed(100 + V)
+    B, Ln = 7, 301
+    for graph in (GL.Absorbing(V - 1), GL.Uniform(V)):
+        absorb = isinstance(graph, GL.Absorbing)
+        x0 = torch.randint(0, V - 1, (B, Ln), device=DEV)
+        x = torch.randint(0, V, (B, Ln), device=DEV)
+        if absorb:
+            x[torch.rand(B, Ln, device=DEV) < 0.5] = V - 1
+        score = (torch.randn(B, Ln, V, device=DEV) * 2 - 1).to(dtype)
+        sigma = torch.rand(B, device=DEV) * 3 + 0.05
+        gw = torch.rand(B, device=DEV)
+        u = torch.rand(B, Ln, V, device=DEV)
+        o1, d1 = ops.score_entropy_fwd(graph, score, sigma, x, x0, gw=gw)
+        o2, d2 = ops.score_entropy_fwd(graph, _misaligned(score), sigma, x, x0, gw=gw)
+        assert torch.equal(o1, o2) and torch.equal(d1, d2)
+        assert torch.equal(ops.gumbel_argmax(score.exp(), u), ops.gumbel_argmax(_misaligned(score.exp()), u))
+        for step in (L.STEP_EULER, L.STEP_ANALYTIC, L.STEP_DENOISE):
+            uu = u[..., :-1].contiguous() if (absorb and step == L.STEP_DENOISE) else u
+            a = ops.predictor_step(graph, step, score, x, sigma, uu)
+            b = ops.predictor_step(graph, step, _misaligned(score), x, sigma, uu)
+            assert torch.equal(a, b), (type(graph).__name__, step)
+
+
 def test_absorbing_unmasked_fixed_point_full_size():
     """SURVEY section 4 KAT at BASELINE config-5 shard size (512 x 1024 rows): Euler/Analytic never move an
     unmasked token, whatever the noise; masked tokens only move to non-mask ids or stay."""

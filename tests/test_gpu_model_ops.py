@@ -176,16 +176,23 @@ def test_gelu_silu_embed_epilogue_colsum_transpose():
         ops.embedding_bwd(dout, idx, dt)
         ref = torch.zeros(V, 768, device=DEV).index_add_(0, idx.reshape(-1), dout.reshape(-1, 768))
         assert rel_err(dt, ref) < 1e-5
-    # logits epilogue
+    # logits epilogue (16-byte chunks straddle rows and batch elements; tail chunk; unaligned base -> scalar kernel)
     for dtype in (torch.float32, torch.bfloat16):
-        lg = torch.randn(4, 33, 26).to(dtype)
-        sg = torch.tensor([0.01, 0.3, 0.7, 5.0])
-        idx = torch.randint(0, 26, (4, 33))
-        ref = O.logits_epilogue(lg, sg, idx)
-        out = ops.logits_epilogue_(lg.to(DEV).clone(), sg.to(DEV), idx.to(DEV))
-        assert rel_err(out.float(), ref.float()) < (1e-6 if dtype == torch.float32 else 8e-3)
-        assert float(out.gather(-1, idx.to(DEV)[..., None]).abs().max()) == 0.0
-        d = ops.logits_epilogue_bwd_(torch.ones(4, 33, 26, device=DEV, dtype=dtype), idx.to(DEV))
+        for (B, Ln, V) in ((4, 33, 26), (5, 1, 3), (3, 7, 37)):
+            lg = torch.randn(B, Ln, V).to(dtype)
+            sg = torch.tensor([0.01, 0.3, 0.7, 5.0, 1.1])[:B]
+            idx = torch.randint(0, V, (B, Ln))
+            ref = O.logits_epilogue(lg, sg, idx)
+            out = ops.logits_epilogue_(lg.to(DEV).clone(), sg.to(DEV), idx.to(DEV))
+            assert rel_err(out.float(), ref.float()) < (1e-6 if dtype == torch.float32 else 8e-3)
+            assert float(out.gather(-1, idx.to(DEV)[..., None]).abs().max()) == 0.0
+            buf = torch.empty(lg.numel() + 8, dtype=dtype, device=DEV)
+            mis = buf[1:1 + lg.numel()].view(lg.shape)
+            mis.copy_(lg)
+            assert torch.equal(ops.logits_epilogue_(mis, sg.to(DEV), idx.to(DEV)), out)
+            nos = ops.logits_epilogue_(lg.to(DEV).clone(), sg.to(DEV), idx.to(DEV), scale_by_sigma=False)
+            assert torch.equal(nos, lg.to(DEV).scatter(-1, idx.to(DEV)[..., None], 0.0))
+        d = ops.logits_epilogue_bwd_(torch.ones(4, 33, 26, device=DEV, dtype=dtype), idx.new_zeros(4, 33).to(DEV))
         assert float(d.float().sum()) == 4 * 33 * 25
     a = torch.randn(777, 130, device=DEV)
     assert rel_err(ops.colsum(a), a.sum(0)) < 1e-5

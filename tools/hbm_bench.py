@@ -38,7 +38,8 @@ for (B, Ln, V, dt) in ((512, 1024, 26, torch.bfloat16), (512, 1024, 26, torch.fl
     report(f"score_entropy fwd {tag}", M * (V * e + 20), ms)
     ms = timeit(lambda: ops.score_entropy_fwd(g, logits, sig, x, x0, gw=sig))
     report(f"score_entropy fwd+bwd {tag}", M * (2 * V * e + 20), ms)
-    ms = timeit(lambda: ops.sample_transition(g, x0, sig, u[..., 0].contiguous()))
+    u1 = u[..., 0].contiguous()
+    ms = timeit(lambda: ops.sample_transition(g, x0, sig, u1))
     report(f"sample_transition {tag}", M * 20, ms)
     ms = timeit(lambda: ops.gumbel_argmax(logits, u))
     report(f"gumbel_argmax {tag}", M * (V * e + V * 4 + 8), ms)
