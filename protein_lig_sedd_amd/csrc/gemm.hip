@@ -17,6 +17,7 @@
 //   configuration and the fp32-autocast cross model.
 // MFMA-bound: 2*M*N*K flop per call.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -189,6 +190,295 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_glds_kernel(const bf16_t* __
     }
 #undef STAGE
     store_tile<TO>(C, ldc, pre, bias, epi, accumulate, gridDim.y > 1, m0, n0, wr, wc, lane, M, N, acc);
+}
+
+
+// ----------------------------------------------------------------- bf16, big-tile multi-stage LDS-DMA path
+// 256 x BN x 32 block tile (BN = 256 or 128), 8 waves (2 per SIMD), NST-deep ring of LDS stages filled by LDS-DMA.
+// A 128x128 tile moves 1 byte per 64 flop from L2 into LDS and can keep only one 64-wide K tile in flight per block,
+// so every K step waits a full memory latency; the 256-wide tile halves the bytes per flop and the ring keeps NST-1
+// K tiles (>= 1 us of MFMA work) in flight.  The ring needs counted waits — s_waitcnt vmcnt(N) leaves the N youngest
+// DMA loads in flight — and a bare s_barrier (a __syncthreads() makes the compiler drain every outstanding LDS-DMA);
+// the K loop is unrolled by NST so every stage is a compile-time LDS offset.
+// LDS rows are 64 B (4 x 16-byte chunks); chunk index XOR ((row >> 1) & 3) makes the ds_read_b128 fragment reads
+// conflict-free (swizzle applied on the DMA source address and on the reads).
+#define BIG_BM 256
+#define BIG_BK 32
+
+// Output staging for the big-tile kernel.  In the MFMA C layout a lane owns 4 consecutive columns of one row, so a
+// direct store writes 32-byte (bf16) row segments and the write path runs at ~1.2 TB/s.  Each wave instead parks 16
+// rows x 64 columns at a time in a private LDS region outside the operand ring (row pitch padded by 16 B:
+// conflict-free writes, 2-way reads) and stores them back out with 16 bytes per lane, 128 contiguous bytes per row.
+// (fp32 outputs already write 64-byte segments from the accumulators and stay direct.)
+template <typename TO> struct StageCfg {
+    static constexpr int RPP = 16;                               // rows per pass (one MFMA fragment row block)
+    static constexpr int PITCH = sizeof(TO) == 2 ? 144 : 272;    // bytes
+    static constexpr int REGION = RPP * PITCH;                   // per-wave LDS bytes
+    static constexpr int LPR = 64 * (int)sizeof(TO) / 16;        // lanes per 64-column row (8 / 16)
+    static constexpr int EPC = 16 / (int)sizeof(TO);             // elements per 16-byte chunk
+};
+template <typename TO>
+__device__ __forceinline__ void stage_put4(unsigned char* reg, int row_l, int col_l, f32x4 v) {
+    store_row4<TO>(reinterpret_cast<TO*>(reg + row_l * StageCfg<TO>::PITCH) + col_l, v);
+}
+// flush one pass: rows [row_g, row_g + RPP) x columns [col_g, col_g + 64) of C; accumulate adds the old C (fp32/bf16)
+template <typename TO>
+__device__ __forceinline__ void stage_flush(const unsigned char* reg, TO* __restrict__ C, int64_t ldc, int64_t row_g,
+                                            int64_t col_g, int64_t M, int64_t N, int lane, int accumulate) {
+    using SC = StageCfg<TO>;
+    constexpr int RPI = 64 / SC::LPR;  // rows per wave-instruction
+    const int rsub = lane / SC::LPR, chunk = lane % SC::LPR;
+#pragma unroll
+    for (int i = 0; i < SC::RPP / RPI; ++i) {
+        const int row_l = i * RPI + rsub;
+        const int64_t gr = row_g + row_l, gc = col_g + chunk * SC::EPC;
+        if (gr >= M || gc >= N) continue;
+        union { uint4 u; TO e[SC::EPC]; } v;
+        v.u = *reinterpret_cast<const uint4*>(reg + row_l * SC::PITCH + chunk * 16);
+        TO* p = C + gr * ldc + gc;
+        if (gc + SC::EPC <= N) {
+            if (accumulate) {
+                union { uint4 u; TO e[SC::EPC]; } o;
+                o.u = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+                for (int e = 0; e < SC::EPC; ++e) v.e[e] = from_f32<TO>(to_f32<TO>(v.e[e]) + to_f32<TO>(o.e[e]));
+            }
+            *reinterpret_cast<uint4*>(p) = v.u;
+        } else {
+            for (int e = 0; e < SC::EPC && gc + e < N; ++e)
+                p[e] = accumulate ? from_f32<TO>(to_f32<TO>(v.e[e]) + to_f32<TO>(p[e])) : v.e[e];
+        }
+    }
+}
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4] and lgkmcnt [11:8] left
+// at "no wait").  The builtin, unlike inline asm, is visible to the compiler's own wait-count bookkeeping, which
+// otherwise assumes the older LDS-DMA loads are still pending and drains vmcnt(0) before the next LDS read.
+template <int N> __device__ __forceinline__ void vm_wait_le() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+// wait until at most `younger` K tiles of LPT loads each are still in flight (younger <= 4)
+template <int LPT> __device__ __forceinline__ void wait_tiles(int younger) {
+    switch (younger) {
+        case 0: vm_wait_le<0>(); break;
+        case 1: vm_wait_le<LPT>(); break;
+        case 2: vm_wait_le<2 * LPT>(); break;
+        case 3: vm_wait_le<3 * LPT>(); break;
+        default: vm_wait_le<4 * LPT>(); break;
+    }
+}
+
+// 16-byte-per-lane LDS-DMA (global -> LDS at lds_addr + 16 * lane, no VGPR round trip), issued from inline asm so
+// that the ring's waits are ours alone: the compiler cannot tell the ring's stages apart and, when it sees the DMA
+// through the builtin, drains vmcnt(0) before LDS reads of OTHER stages.  Unknown to its bookkeeping, these loads can
+// only make the compiler's own vmcnt waits stricter (vmcnt counts in issue order), never too weak.
+__device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+
+template <typename TO, int BN_, int NST>
+__global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                               const bf16_t* __restrict__ B, int64_t ldb,
+                                                               TO* __restrict__ C, int64_t ldc,
+                                                               const float* __restrict__ bias, int epi,
+                                                               TO* __restrict__ pre, int accumulate, int64_t M,
+                                                               int64_t N, int64_t Kper, int ntn, int ntiles) {
+    constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
+    constexpr int LA = 2, LB = BN_ / 128, LPT = LA + LB;              // DMA wave-instructions per stage
+    constexpr int ASLOTS = BIG_BM * 4, SLOTS = (BIG_BM + BN_) * 4;    // 16-byte slots per stage
+    constexpr int TMH = TM / 2;
+    constexpr bool STAGED = sizeof(TO) == 2;                          // bf16 outputs leave through the staging region
+    static_assert(NST >= 4 && NST <= 6 && NST % 2 == 0, "ring depth (even: the fragment register sets alternate)");
+    __shared__ __attribute__((aligned(16))) uint4 smem[NST][SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_lds[STAGED ? 8 * StageCfg<TO>::REGION : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t kbeg = (int64_t)blockIdx.y * Kper;
+    const int nkt = (int)(Kper / BIG_BK);
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&smem[0][0];
+    // fragment read offsets: lane -> row (lane & 15) of a 16-row fragment, k chunk (lane >> 4), swizzled
+    const int r15 = lane & 15;
+    const int fa = (wm * TM * 16 + r15) * 4 + ((lane >> 4) ^ ((r15 >> 1) & 3));
+    const int fb = ASLOTS + (wn * 64 + r15) * 4 + ((lane >> 4) ^ ((r15 >> 1) & 3));
+    const bool vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (!pre || (reinterpret_cast<uintptr_t>(pre) & 15) == 0);
+    const bool staged = STAGED && gridDim.y == 1 && !accumulate && (ldc * sizeof(TO)) % 16 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (!pre || (reinterpret_cast<uintptr_t>(pre) & 15) == 0);
+
+    // one DMA wave-instruction fills 16 rows x 64 B; lane -> (row, LDS chunk) = (lane >> 2, lane & 3)
+    const bf16_t* srcA[LA];
+    const bf16_t* srcB[LB];
+    int64_t m0 = 0, n0 = 0;
+#define BIG_TILE_SETUP(tile)                                                                                         \
+    do {                                                                                                             \
+        const int wg_ = xcd_remap((int)(tile), ntiles);                                                              \
+        m0 = (int64_t)(wg_ / ntn) * BIG_BM;                                                                          \
+        n0 = (int64_t)(wg_ % ntn) * BN_;                                                                             \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
+            const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                         \
+            const int c = (lane & 3) ^ ((r >> 1) & 3);                                                               \
+            int64_t ar = m0 + r;                                                                                     \
+            ar = ar < M ? ar : M - 1;                                                                                \
+            srcA[i] = A + ar * lda + kbeg + c * 8;                                                                   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                             \
+            const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                         \
+            const int c = (lane & 3) ^ ((r >> 1) & 3);                                                               \
+            int64_t br = n0 + r;                                                                                     \
+            br = br < N ? br : N - 1;                                                                                \
+            srcB[i] = B + br * ldb + kbeg + c * 8;                                                                   \
+        }                                                                                                            \
+    } while (0)
+#define BIG_STAGE(st, kt)                                                                                            \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                               \
+            lds_dma16(srcA[i] + (int64_t)(kt) * BIG_BK, ring + ((st) * SLOTS + (i * 8 + wave) * 64) * 16);           \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i)                                                               \
+            lds_dma16(srcB[i] + (int64_t)(kt) * BIG_BK, ring + ((st) * SLOTS + ASLOTS + (i * 8 + wave) * 64) * 16);  \
+    } while (0)
+#define BIG_PROLOGUE()                                                                                               \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < NST - 1; ++s)                                                          \
+            if (s < nkt) BIG_STAGE(s, s);                                                                            \
+    } while (0)
+#define BIG_READ_A(dst, st, mbase)                                                                                   \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int m = 0; m < TMH; ++m) dst[m] =                                                     \
+            *reinterpret_cast<const bf16x8*>(&smem[st][fa + ((mbase) + m) * 64]);                                    \
+    } while (0)
+#define BIG_READ_B(set, st)                                                                                          \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) b[set][n] =                                                    \
+            *reinterpret_cast<const bf16x8*>(&smem[st][fb + n * 64]);                                                \
+    } while (0)
+#define BIG_MMA(asrc, mbase, set)                                                                                    \
+    do {                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        _Pragma("unroll") for (int m = 0; m < TMH; ++m)                                                              \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                            \
+                acc[(mbase) + m][n] =                                                                                \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[set][n], asrc[m], acc[(mbase) + m][n], 0, 0, 0);       \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+    } while (0)
+
+    // persistent over output tiles: the next tile's first K tiles are in flight while this tile's results leave
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    BIG_TILE_SETUP(tile);
+    BIG_PROLOGUE();
+    while (true) {
+        f32x4 acc[TM][4];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Fragment registers are pipelined at half-stage granularity: while the lower half of the A fragments
+        // multiplies, the upper half is read; while the upper half multiplies, the next K tile's lower half and B
+        // fragments are read (B is double-buffered, A's halves alternate) — 64 fragment registers instead of 96.
+        bf16x8 a_lo[TMH], a_hi[TMH], b[2][4];
+        // first K tile of this output tile: everything older (the previous tile's stores included) must have drained
+        wait_tiles<LPT>(nkt - 1 < NST - 2 ? nkt - 1 : NST - 2);
+        __builtin_amdgcn_s_barrier();
+        BIG_READ_A(a_lo, 0, 0);
+        BIG_READ_B(0, 0);
+        for (int kt0 = 0; kt0 < nkt; kt0 += NST) {
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const int kt = kt0 + s;
+                if (kt < nkt) {
+                    BIG_READ_A(a_hi, s, TMH);
+                    BIG_MMA(a_lo, 0, s & 1);
+                    if (kt + 1 < nkt) {
+                        const int rem = nkt - 2 - kt;
+                        wait_tiles<LPT>(rem < NST - 3 ? rem : NST - 3);  // K tile kt+1 has landed (this wave's share)
+                        __builtin_amdgcn_s_barrier();  // ... every wave's share; the stage of tile kt-1 is consumed
+                        if (kt + NST - 1 < nkt) BIG_STAGE((s + NST - 1) % NST, kt + NST - 1);
+                        BIG_READ_A(a_lo, (s + 1) % NST, 0);
+                        BIG_READ_B((s + 1) & 1, (s + 1) % NST);
+                    }
+                    BIG_MMA(a_hi, TMH, s & 1);
+                }
+            }
+        }
+        const int64_t row_t = m0 + wm * TM * 16, col_w = n0 + wn * 64;
+        const int next = tile + gridDim.x;
+        // the ring is free once every wave has issued its last MFMAs: start the next tile's loads under the epilogue
+        __builtin_amdgcn_s_barrier();
+        if (next < ntiles) {
+            BIG_TILE_SETUP(next);
+            BIG_PROLOGUE();
+        }
+        if (!staged) {  // fp32 / split-K atomics / accumulate / unaligned C: straight from the accumulators
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, gridDim.y > 1, row_t + m * 16 + (lane & 15),
+                                  col_w + n * 16 + 4 * (lane >> 4), M, N, acc[m][n], vec_ok);
+        } else if constexpr (STAGED) {
+            using SC = StageCfg<TO>;
+            constexpr int FPP = SC::RPP / 16;  // 16-row fragments per pass
+            unsigned char* reg = stage_lds + wave * SC::REGION;
+            float4 bv[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bv[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (epi != SEDD_EPI_NONE) {
+                    const int64_t c = col_w + n * 16 + 4 * (lane >> 4);
+                    bv[n].x = c + 0 < N ? bias[c + 0] : 0.f;
+                    bv[n].y = c + 1 < N ? bias[c + 1] : 0.f;
+                    bv[n].z = c + 2 < N ? bias[c + 2] : 0.f;
+                    bv[n].w = c + 3 < N ? bias[c + 3] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int pass = 0; pass < TM / FPP; ++pass) {
+                const int64_t row_w = row_t + pass * SC::RPP;
+                if (epi == SEDD_EPI_BIAS_GELU) {
+                    // the reference rounds the Linear output to the activation dtype before GELU; `pre` keeps it
+#pragma unroll
+                    for (int mm = 0; mm < FPP; ++mm)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            f32x4& v = acc[pass * FPP + mm][n];
+                            v[0] = to_f32<TO>(from_f32<TO>(v[0] + bv[n].x));
+                            v[1] = to_f32<TO>(from_f32<TO>(v[1] + bv[n].y));
+                            v[2] = to_f32<TO>(from_f32<TO>(v[2] + bv[n].z));
+                            v[3] = to_f32<TO>(from_f32<TO>(v[3] + bv[n].w));
+                            if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), v);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                        }
+                    if (pre) stage_flush<TO>(reg, pre, ldc, row_w, col_w, M, N, lane, 0);
+                } else if (epi == SEDD_EPI_BIAS) {
+#pragma unroll
+                    for (int mm = 0; mm < FPP; ++mm)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            f32x4& v = acc[pass * FPP + mm][n];
+                            v[0] += bv[n].x; v[1] += bv[n].y; v[2] += bv[n].z; v[3] += bv[n].w;
+                        }
+                }
+#pragma unroll
+                for (int mm = 0; mm < FPP; ++mm)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), acc[pass * FPP + mm][n]);
+                stage_flush<TO>(reg, C, ldc, row_w, col_w, M, N, lane, 0);
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+    }
+#undef BIG_MMA
+#undef BIG_READ_B
+#undef BIG_READ_A
+#undef BIG_PROLOGUE
+#undef BIG_STAGE
+#undef BIG_TILE_SETUP
 }
 
 // ------------------------------------------------------------------------------- bf16, generic register-staged
@@ -368,7 +658,36 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     const dim3 grid((unsigned)(ntm * ntn));
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == SEDD_BF16) {
-        if (K % BK16 == 0) {
+        // big-tile path: 256 x 256 or 256 x 128 tiles, whichever quantises better onto the 256 CUs
+        if (K % BIG_BK == 0 && M >= 192 && N >= 96 && !getenv("SEDD_GEMM_SMALL_TILES")) {
+            const int64_t tm = (M + BIG_BM - 1) / BIG_BM;
+            const int64_t t256 = tm * ((N + 255) / 256), t128 = tm * ((N + 127) / 128);
+            // cost ~ (number of chip-wide rounds) x (tile work); the 256-wide tile does twice the work per round
+            const double c256 = (double)((t256 + 255) / 256) * 2.0, c128 = (double)((t128 + 255) / 256) * 1.05;
+            const bool wide = N > 128 && c256 <= c128;
+            const int bn = wide ? 256 : 128;
+            const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
+            int splitk = 1;
+            if (accumulate && out_dtype == SEDD_F32) {
+                const int64_t nkt = K / BIG_BK;
+                while (tiles * splitk < 256 && nkt % (splitk * 2) == 0 && nkt / (splitk * 2) >= 16) splitk *= 2;
+            }
+            SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_nt: too many tiles");
+            // one persistent block per CU (the operand ring takes most of a CU's LDS)
+            const dim3 g2((unsigned)(tiles < 256 ? tiles : 256), (unsigned)splitk);
+#define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
+    hipLaunchKernelGGL((gemm_bf16_nt_big_kernel<TO, BN_, NST>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,         \
+                       (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, K / splitk,   \
+                       (int)tn, (int)tiles)
+            if (out_dtype == SEDD_BF16) {
+                if (wide) BIG_LAUNCH(bf16_t, 256, 4);
+                else BIG_LAUNCH(bf16_t, 128, 4);
+            } else {
+                if (wide) BIG_LAUNCH(float, 256, 4);
+                else BIG_LAUNCH(float, 128, 6);
+            }
+#undef BIG_LAUNCH
+        } else if (K % BK16 == 0) {
             // split K across blockIdx.y for accumulating fp32 outputs with too few tiles to fill 256 CUs
             int splitk = 1;
             if (accumulate && out_dtype == SEDD_F32) {

@@ -38,7 +38,8 @@ def test_gemm_fp32(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (64, 4608, 128), (2048, 26, 768), (512, 768, 3072),
-                                   (257, 129, 776)])
+                                   (257, 129, 776), (256, 256, 32), (300, 200, 96), (1000, 130, 160), (777, 515, 224),
+                                   (768, 2304, 8192), (192, 96, 64)])
 def test_gemm_bf16(M, N, K):
     ops = _ops()
     torch.manual_seed(M + N + K)
