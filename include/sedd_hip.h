@@ -168,6 +168,19 @@ int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n,
 int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
                  int64_t K, sedd_stream_t stream);
+/* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
+ * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
+ * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no
+ * transposed copies are made.  bf16 operands only, fp32 accumulation, C fp32 or bf16; accumulate != 0 adds into an
+ * fp32 C (the flat gradient buffer).  An output with too few 256-wide tiles for the chip is split along K: with a
+ * caller-owned `workspace` (16-byte aligned, workspace_bytes >= 256 MiB always suffices; exactly
+ * slices * tiles * 256 * tile_width * 4 with slices * tiles <= 256) the slices park fp32 partial tiles there and a
+ * second launch sums them into C; with workspace == NULL an accumulating call falls back to fp32 atomics.
+ * Requirements: K % 32 == 0, M % 8 == 0, N % 8 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned bases; otherwise
+ * SEDD_ERR_UNSUPPORTED_SHAPE (callers fall back to sedd_transpose + sedd_gemm_nt). */
+int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                 int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
+                 int64_t workspace_bytes, sedd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ attention
  * The flash-attn boundary (transformer.py:172-183: flash_attn_varlen_qkvpacked_func, non-causal, no dropout,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sedd_transpose": "pilpilllp",
     "sedd_cast": "pipilp",
     "sedd_gemm_nt": "plplpliipipilllp",
+    "sedd_gemm_tn": "plplpliiilllplp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "i" + "f" + "lp",

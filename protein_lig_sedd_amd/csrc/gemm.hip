@@ -22,6 +22,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define BM 128
 #define BN 128
@@ -277,13 +278,21 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
 }
 
-template <typename TO, int BN_, int NST>
-__global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                               const bf16_t* __restrict__ B, int64_t ldb,
-                                                               TO* __restrict__ C, int64_t ldc,
-                                                               const float* __restrict__ bias, int epi,
-                                                               TO* __restrict__ pre, int accumulate, int64_t M,
-                                                               int64_t N, int64_t Kper, int ntn, int ntiles) {
+// TN = false: C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous (forward / data gradients).
+// TN = true : C[M,N] = A[K,M]^T * B[K,N], both operands stored with the reduction index as the ROW (weight gradients:
+//   A = dY [tokens, out], B = X [tokens, in]) — no transposed copies.  A stage holds 32 token rows of each operand as
+//   they lie in memory (512-byte / 2*BN-byte rows, 16-byte chunk index XOR 2*(row & 7) against bank conflicts); the
+//   k-contiguous MFMA fragments come out of LDS through the transposing read ds_read_b64_tr_b16, which hands lane
+//   (g, i) the four rows 4g..4g+3 of column i: a fragment is two of them (rows 4g+j and 16+4g+j) — a permutation of the
+//   32 k values that both operands share, which a sum over k allows.
+template <typename TO, int BN_, int NST, bool TN>
+__global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                            const bf16_t* __restrict__ B, int64_t ldb,
+                                                            TO* __restrict__ C, int64_t ldc,
+                                                            const float* __restrict__ bias, int epi,
+                                                            TO* __restrict__ pre, int accumulate, int64_t M,
+                                                            int64_t N, int64_t Kper, int64_t Ktot, int ntn,
+                                                            int ntiles, int splitk, float4* __restrict__ slabs) {
     constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
     constexpr int LA = 2, LB = BN_ / 128, LPT = LA + LB;              // DMA wave-instructions per stage
     constexpr int ASLOTS = BIG_BM * 4, SLOTS = (BIG_BM + BN_) * 4;    // 16-byte slots per stage
@@ -295,16 +304,25 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t kbeg = (int64_t)blockIdx.y * Kper;
-    const int nkt = (int)(Kper / BIG_BK);
+    // Split-K launches are 1-D over (K slice, tile) with the slice as the slow index of the XCD-contiguous order: the
+    // ~tiles*splitk/8 blocks that share an XCD's L2 then work on the same K slice, i.e. on the same operand panels.
+    const int work = splitk > 1 ? xcd_remap(blockIdx.x, gridDim.x) : 0;
+    const int64_t kbeg = (int64_t)(work / ntiles) * Kper;
+    const int nkt = (int)((Ktot - kbeg < Kper ? Ktot - kbeg : Kper) / BIG_BK);
+    const int64_t ksA = TN ? BIG_BK * lda : BIG_BK, ksB = TN ? BIG_BK * ldb : BIG_BK;  // operand advance per K tile
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&smem[0][0];
     // fragment read offsets: lane -> row (lane & 15) of a 16-row fragment, k chunk (lane >> 4), swizzled
     const int r15 = lane & 15;
     const int fa = (wm * TM * 16 + r15) * 4 + ((lane >> 4) ^ ((r15 >> 1) & 3));
     const int fb = ASLOTS + (wn * 64 + r15) * 4 + ((lane >> 4) ^ ((r15 >> 1) & 3));
+    // TN: transposing reads. lane = 16 g + 4 q + p supplies the address of row 4g+q, columns 4p..4p+3 of a 16-column block
+    constexpr int PB = BN_ * 2;  // bytes per B row in a TN stage
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, tyc = 4 * (tg & 1) + tq;
+    const int ta = (4 * tg + tq) * 512 + (tp >> 1) * 16 + (tp & 1) * 8;
+    const int tb = ASLOTS * 16 + (4 * tg + tq) * PB + (tp >> 1) * 16 + (tp & 1) * 8;
     const bool vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!pre || (reinterpret_cast<uintptr_t>(pre) & 15) == 0);
-    const bool staged = STAGED && gridDim.y == 1 && !accumulate && (ldc * sizeof(TO)) % 16 == 0 &&
+    const bool staged = STAGED && splitk == 1 && !accumulate && (ldc * sizeof(TO)) % 16 == 0 &&
                         ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!pre || (reinterpret_cast<uintptr_t>(pre) & 15) == 0);
 
@@ -314,45 +332,80 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __r
     int64_t m0 = 0, n0 = 0;
 #define BIG_TILE_SETUP(tile)                                                                                         \
     do {                                                                                                             \
-        const int wg_ = xcd_remap((int)(tile), ntiles);                                                              \
+        const int wg_ = splitk > 1 ? (int)(tile) : xcd_remap((int)(tile), ntiles);                                   \
         m0 = (int64_t)(wg_ / ntn) * BIG_BM;                                                                          \
         n0 = (int64_t)(wg_ % ntn) * BN_;                                                                             \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
-            const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                         \
-            const int c = (lane & 3) ^ ((r >> 1) & 3);                                                               \
-            int64_t ar = m0 + r;                                                                                     \
-            ar = ar < M ? ar : M - 1;                                                                                \
-            srcA[i] = A + ar * lda + kbeg + c * 8;                                                                   \
+            if constexpr (TN) { /* wave-instruction j = 2 token rows x 512 B */                                      \
+                const int r = (i * 8 + wave) * 2 + (lane >> 5);                                                      \
+                int64_t col = m0 + (((lane & 31) ^ (2 * (r & 7))) << 3);                                             \
+                col = col < M ? col : 0;                                                                             \
+                srcA[i] = A + (kbeg + r) * lda + col;                                                                \
+            } else {                                                                                                 \
+                const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                     \
+                const int c = (lane & 3) ^ ((r >> 1) & 3);                                                           \
+                int64_t ar = m0 + r;                                                                                 \
+                ar = ar < M ? ar : M - 1;                                                                            \
+                srcA[i] = A + ar * lda + kbeg + c * 8;                                                               \
+            }                                                                                                        \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                             \
-            const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                         \
-            const int c = (lane & 3) ^ ((r >> 1) & 3);                                                               \
-            int64_t br = n0 + r;                                                                                     \
-            br = br < N ? br : N - 1;                                                                                \
-            srcB[i] = B + br * ldb + kbeg + c * 8;                                                                   \
+            if constexpr (TN) {                                                                                      \
+                constexpr int CPR = BN_ / 8; /* 16-byte chunks per B row */                                          \
+                const int r = (i * 8 + wave) * (64 / CPR) + lane / CPR;                                              \
+                int64_t col = n0 + (((lane % CPR) ^ (2 * (r & 7))) << 3);                                            \
+                col = col < N ? col : 0;                                                                             \
+                srcB[i] = B + (kbeg + r) * ldb + col;                                                                \
+            } else {                                                                                                 \
+                const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                     \
+                const int c = (lane & 3) ^ ((r >> 1) & 3);                                                           \
+                int64_t br = n0 + r;                                                                                 \
+                br = br < N ? br : N - 1;                                                                            \
+                srcB[i] = B + br * ldb + kbeg + c * 8;                                                               \
+            }                                                                                                        \
         }                                                                                                            \
     } while (0)
 #define BIG_STAGE(st, kt)                                                                                            \
     do {                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                               \
-            lds_dma16(srcA[i] + (int64_t)(kt) * BIG_BK, ring + ((st) * SLOTS + (i * 8 + wave) * 64) * 16);           \
+            lds_dma16(srcA[i] + (int64_t)(kt) * ksA, ring + ((st) * SLOTS + (i * 8 + wave) * 64) * 16);              \
         _Pragma("unroll") for (int i = 0; i < LB; ++i)                                                               \
-            lds_dma16(srcB[i] + (int64_t)(kt) * BIG_BK, ring + ((st) * SLOTS + ASLOTS + (i * 8 + wave) * 64) * 16);  \
+            lds_dma16(srcB[i] + (int64_t)(kt) * ksB, ring + ((st) * SLOTS + ASLOTS + (i * 8 + wave) * 64) * 16);     \
     } while (0)
 #define BIG_PROLOGUE()                                                                                               \
     do {                                                                                                             \
         _Pragma("unroll") for (int s = 0; s < NST - 1; ++s)                                                          \
             if (s < nkt) BIG_STAGE(s, s);                                                                            \
     } while (0)
+#define BIG_TR(st, off) __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                                     \
+        (__attribute__((address_space(3))) s16x4*)(reinterpret_cast<unsigned char*>(&smem[st][0]) + (off)))
 #define BIG_READ_A(dst, st, mbase)                                                                                   \
     do {                                                                                                             \
-        _Pragma("unroll") for (int m = 0; m < TMH; ++m) dst[m] =                                                     \
-            *reinterpret_cast<const bf16x8*>(&smem[st][fa + ((mbase) + m) * 64]);                                    \
+        _Pragma("unroll") for (int m = 0; m < TMH; ++m) {                                                            \
+            if constexpr (TN) {                                                                                      \
+                const int o_ = ta + (((wm * TM + (mbase) + m) ^ tyc) << 5);                                          \
+                union { struct { s16x4 lo, hi; } s; bf16x8 v; } f_;                                                  \
+                f_.s.lo = BIG_TR(st, o_);                                                                            \
+                f_.s.hi = BIG_TR(st, o_ + 16 * 512);                                                                 \
+                dst[m] = f_.v;                                                                                       \
+            } else {                                                                                                 \
+                dst[m] = *reinterpret_cast<const bf16x8*>(&smem[st][fa + ((mbase) + m) * 64]);                       \
+            }                                                                                                        \
+        }                                                                                                            \
     } while (0)
 #define BIG_READ_B(set, st)                                                                                          \
     do {                                                                                                             \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n) b[set][n] =                                                    \
-            *reinterpret_cast<const bf16x8*>(&smem[st][fb + n * 64]);                                                \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                              \
+            if constexpr (TN) {                                                                                      \
+                const int o_ = tb + (((wn * 4 + n) ^ tyc) << 5);                                                     \
+                union { struct { s16x4 lo, hi; } s; bf16x8 v; } f_;                                                  \
+                f_.s.lo = BIG_TR(st, o_);                                                                            \
+                f_.s.hi = BIG_TR(st, o_ + 16 * PB);                                                                  \
+                b[set][n] = f_.v;                                                                                    \
+            } else {                                                                                                 \
+                b[set][n] = *reinterpret_cast<const bf16x8*>(&smem[st][fb + n * 64]);                                \
+            }                                                                                                        \
+        }                                                                                                            \
     } while (0)
 #define BIG_MMA(asrc, mbase, set)                                                                                    \
     do {                                                                                                             \
@@ -365,7 +418,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __r
     } while (0)
 
     // persistent over output tiles: the next tile's first K tiles are in flight while this tile's results leave
-    int tile = blockIdx.x;
+    int tile = splitk > 1 ? work % ntiles : (int)blockIdx.x;
     if (tile >= ntiles) return;
     BIG_TILE_SETUP(tile);
     BIG_PROLOGUE();
@@ -404,19 +457,28 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __r
             }
         }
         const int64_t row_t = m0 + wm * TM * 16, col_w = n0 + wn * 64;
-        const int next = tile + gridDim.x;
+        const int next = splitk > 1 ? ntiles : tile + (int)gridDim.x;
         // the ring is free once every wave has issued its last MFMAs: start the next tile's loads under the epilogue
         __builtin_amdgcn_s_barrier();
         if (next < ntiles) {
             BIG_TILE_SETUP(next);
             BIG_PROLOGUE();
         }
-        if (!staged) {  // fp32 / split-K atomics / accumulate / unaligned C: straight from the accumulators
+        if (splitk > 1 && slabs) {
+            // split-K partial tile: parked in the workspace in register order (every store a contiguous 1 KiB per wave);
+            // splitk_reduce_kernel sums the slices and applies them to C
+            float4* dst = slabs + ((int64_t)(work / ntiles) * ntiles + tile) * (BIG_BM * BN_ / 4) + wave * TM * 4 * 64 + lane;
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, gridDim.y > 1, row_t + m * 16 + (lane & 15),
+                    dst[(m * 4 + n) * 64] = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+        } else if (!staged) {  // fp32 / split-K atomics / accumulate / unaligned C: straight from the accumulators
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, splitk > 1, row_t + m * 16 + (lane & 15),
                                   col_w + n * 16 + 4 * (lane >> 4), M, N, acc[m][n], vec_ok);
         } else if constexpr (STAGED) {
             using SC = StageCfg<TO>;
@@ -476,6 +538,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_nt_big_kernel(const bf16_t* __r
 #undef BIG_MMA
 #undef BIG_READ_B
 #undef BIG_READ_A
+#undef BIG_TR
 #undef BIG_PROLOGUE
 #undef BIG_STAGE
 #undef BIG_TILE_SETUP
@@ -636,6 +699,49 @@ __global__ void __launch_bounds__(256) gemm_f32_nt_kernel(const float* __restric
                               n0 + wc * 64 + n * 32 + (lane & 31), M, N, acc[m][n][r]);
 }
 
+
+// second pass of a split-K product: C (+)= sum over K slices of the partial tiles parked by gemm_bf16_big_kernel.
+// One thread per float4 of a tile in the kernel's register order: position = ((wave * TM + m) * 4 + n) * 64 + lane.
+template <int BN_>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float4* __restrict__ slabs, float* __restrict__ C,
+                                                            int64_t ldc, int64_t M, int64_t N, int ntn, int ntiles,
+                                                            int splitk, int accumulate) {
+    constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16, PPT = BIG_BM * BN_ / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)ntiles * PPT) return;
+    const int tile = (int)(idx / PPT), pos = (int)(idx % PPT);
+    float4 s = slabs[(int64_t)tile * PPT + pos];
+    for (int k = 1; k < splitk; ++k) {
+        const float4 v = slabs[((int64_t)k * ntiles + tile) * PPT + pos];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int lane = pos & 63, frag = pos >> 6, n = frag & 3, m = (frag >> 2) % TM, wave = frag / (4 * TM);
+    const int64_t row = (int64_t)(tile / ntn) * BIG_BM + (wave / WN) * TM * 16 + m * 16 + (lane & 15);
+    const int64_t col = (int64_t)(tile % ntn) * BN_ + (wave % WN) * 64 + n * 16 + 4 * (lane >> 4);
+    if (row >= M || col >= N) return;
+    float* p = C + row * ldc + col;
+    const float v[4] = {s.x, s.y, s.z, s.w};
+    if (col + 4 <= N && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        float4 o = accumulate ? *reinterpret_cast<float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        *reinterpret_cast<float4*>(p) = o;
+    } else {
+        for (int r = 0; r < 4 && col + r < N; ++r) p[r] = accumulate ? p[r] + v[r] : v[r];
+    }
+}
+
+// split-K plan for accumulating fp32 outputs with too few tiles for the 256 CUs: as many K slices as keep
+// tiles * slices <= 256 (one round of persistent blocks), every slice a whole number of K tiles, at least 16 of them
+static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
+    const int64_t nkt = K / BIG_BK;
+    int64_t sk = tiles > 0 ? 256 / tiles : 1;
+    if (sk > nkt / 16) sk = nkt / 16;
+    if (sk < 1) sk = 1;
+    const int64_t per = (nkt + sk - 1) / sk;
+    *splitk = (int)((nkt + per - 1) / per);
+    *kper = per * BIG_BK;
+}
+
 extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                             int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
                             int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
@@ -667,18 +773,16 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
             const bool wide = N > 128 && c256 <= c128;
             const int bn = wide ? 256 : 128;
             const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
+            int64_t kper = K;
             int splitk = 1;
-            if (accumulate && out_dtype == SEDD_F32) {
-                const int64_t nkt = K / BIG_BK;
-                while (tiles * splitk < 256 && nkt % (splitk * 2) == 0 && nkt / (splitk * 2) >= 16) splitk *= 2;
-            }
+            if (accumulate && out_dtype == SEDD_F32) big_splitk(tiles, K, &splitk, &kper);
             SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_nt: too many tiles");
             // one persistent block per CU (the operand ring takes most of a CU's LDS)
-            const dim3 g2((unsigned)(tiles < 256 ? tiles : 256), (unsigned)splitk);
+            const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_nt_big_kernel<TO, BN_, NST>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,         \
-                       (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, K / splitk,   \
-                       (int)tn, (int)tiles)
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
+                       (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \
+                       (int)tn, (int)tiles, splitk, (float4*)nullptr)
             if (out_dtype == SEDD_BF16) {
                 if (wide) BIG_LAUNCH(bf16_t, 256, 4);
                 else BIG_LAUNCH(bf16_t, 128, 4);
@@ -722,5 +826,70 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
                                (int)ntn);
     }
     SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations
+// (dW[out,in] = dY[tokens,out]^T X[tokens,in]), no transposed copies.  bf16 operands, fp32 or bf16 C.
+extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                            int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
+                            int64_t workspace_bytes, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(out_dtype == SEDD_F32 || out_dtype == SEDD_BF16, "gemm_tn: bad dtype");
+    SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_tn: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    if (in_dtype != SEDD_BF16 || K % BIG_BK || M % 8 || N % 8 || lda % 8 || ldb % 8 || ((uintptr_t)A & 15) ||
+        ((uintptr_t)B & 15) || lda < M || ldb < N || ldc < N) {
+        sedd_set_error("gemm_tn: unsupported operands (bf16 only; K %% 32, M %% 8, N %% 8, lda %% 8, ldb %% 8 must be 0, "
+                       "16-byte aligned bases): M=%ld N=%ld K=%ld lda=%ld ldb=%ld", (long)M, (long)N, (long)K, (long)lda,
+                       (long)ldb);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0 || N == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tm = (M + BIG_BM - 1) / BIG_BM;
+    const int64_t t256 = tm * ((N + 255) / 256), t128 = tm * ((N + 127) / 128);
+    // few, long tiles: prefer the tile width that leaves the finer split-K granularity
+    const bool wide = N > 128 && (t256 >= 128 || t128 > 256 || N % 256 == 0);
+    const int bn = wide ? 256 : 128;
+    const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
+    SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_tn: too many tiles");
+    int64_t kper = K;
+    int splitk = 1;
+    // K is split when the output has too few tiles for the chip.  With a workspace the slices park their partial
+    // tiles there and a second pass sums them (any fp32 C); without one they add into C with fp32 atomics, which
+    // needs an accumulating call (C already holds valid numbers) and is several times slower at 7+ adders per address.
+    const bool can_split = out_dtype == SEDD_F32 && (accumulate || workspace);
+    if (can_split) big_splitk(tiles, K, &splitk, &kper);
+    float4* slabs = nullptr;
+    if (splitk > 1) {
+        const int64_t need = (int64_t)splitk * tiles * BIG_BM * bn * 4;
+        if (workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) slabs = (float4*)workspace;
+        else if (!accumulate) { splitk = 1; kper = K; }
+    }
+    const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
+#define TN_LAUNCH(TO, BN_)                                                                                           \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
+                       (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs)
+    if (out_dtype == SEDD_BF16) {
+        if (wide) TN_LAUNCH(bf16_t, 256);
+        else TN_LAUNCH(bf16_t, 128);
+    } else {
+        if (wide) TN_LAUNCH(float, 256);
+        else TN_LAUNCH(float, 128);
+    }
+#undef TN_LAUNCH
+    SEDD_LAUNCH_CHECK();
+    if (slabs) {
+        const int64_t n4 = tiles * BIG_BM * bn / 4;
+        const dim3 gr((unsigned)((n4 + 255) / 256));
+        if (wide)
+            hipLaunchKernelGGL((splitk_reduce_kernel<256>), gr, dim3(256), 0, st, (const float4*)slabs, (float*)C, ldc, M,
+                               N, (int)tn, (int)tiles, splitk, accumulate);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<128>), gr, dim3(256), 0, st, (const float4*)slabs, (float*)C, ldc, M,
+                               N, (int)tn, (int)tiles, splitk, accumulate);
+        SEDD_LAUNCH_CHECK();
+    }
     return SEDD_OK;
 }

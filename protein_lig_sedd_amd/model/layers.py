@@ -64,14 +64,21 @@ def linear_fwd(x2d, W, bias=None, gelu=False, want_pre=False, out_dtype=None):
 def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
     """-> (dx [M, K] or None, dW for autograd or None, db for autograd or None)."""
     align = 8 if dy2d.dtype == torch.bfloat16 else 4
-    dyT = transpose_padded(dy2d, align)
-    xT = transpose_padded(x2d, align)
     sink = _sink(W)
-    if sink is not None:
-        ops.gemm_nt(dyT, xT, out=sink, accumulate=True)
-        dW = None
+    if ops.gemm_tn_supported(dy2d, x2d):  # dW = dY^T X straight from the row-major activations
+        if sink is not None:
+            ops.gemm_tn(dy2d, x2d, out=sink, accumulate=True)
+            dW = None
+        else:
+            dW = ops.gemm_tn(dy2d, x2d, out_dtype=torch.float32)
     else:
-        dW = ops.gemm_nt(dyT, xT, out_dtype=torch.float32)
+        dyT = transpose_padded(dy2d, align)
+        xT = transpose_padded(x2d, align)
+        if sink is not None:
+            ops.gemm_nt(dyT, xT, out=sink, accumulate=True)
+            dW = None
+        else:
+            dW = ops.gemm_nt(dyT, xT, out_dtype=torch.float32)
     db = None
     if bias is not None:
         bs = _sink(bias)

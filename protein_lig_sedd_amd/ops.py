@@ -379,6 +379,45 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
     return (out, pre) if (gelu and want_pre) else out
 
 
+def gemm_tn_supported(A, B):
+    """whether sedd_gemm_tn takes these operands (else: transpose + gemm_nt)."""
+    K, M = A.shape
+    N = B.shape[1]
+    return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 32 == 0 and M % 8 == 0 and N % 8 == 0
+            and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+_TN_WS = {}
+
+
+def _tn_workspace(device):
+    """split-K scratch for sedd_gemm_tn: 256 partial tiles of 256 x 256 fp32 (64 MiB), one per device and stream user;
+    launches on one stream are ordered, so consecutive calls may share it."""
+    ws = _TN_WS.get(device)
+    if ws is None:
+        ws = torch.empty(256 * 256 * 256, dtype=torch.float32, device=device)
+        _TN_WS[device] = ws
+    return ws
+
+
+def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):
+    """C[M,N] (+)= A[K,M]^T @ B[K,N] (weight gradient: A = dY [tokens, out], B = X [tokens, in]); bf16 operands."""
+    K, M = A.shape
+    K2, N = B.shape
+    if K != K2 or A.dtype != B.dtype:
+        raise ValueError(f"gemm_tn: A {tuple(A.shape)} {A.dtype} vs B {tuple(B.shape)} {B.dtype}")
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype or torch.float32, device=A.device)
+        accumulate = False
+    ws = _tn_workspace(A.device) if out.dtype == torch.float32 else None
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                 1 if accumulate else 0, M, N, K, _p(ws), 0 if ws is None else ws.numel() * 4,
+                                 _stream()), "sedd_gemm_tn")
+    return out
+
+
 # --------------------------------------------------------------------------------------------- attention
 def _attn_strides(t):
     """t: [B, L, H, d] view with contiguous last dim and head stride d -> (batch stride, seq stride)."""

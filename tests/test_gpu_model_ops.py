@@ -65,6 +65,32 @@ def test_gemm_bf16(M, N, K):
                    wide[:, 32:32 + K].double() @ B.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N", [(32, 256, 256), (64, 96, 128), (4096, 768, 3072), (1024, 2304, 768), (160, 200, 136),
+                                   (8192, 776, 520), (96, 8, 8)])
+def test_gemm_tn_bf16(K, M, N):
+    """weight-gradient GEMM C = A^T B from row-major [tokens, features] operands (transposing LDS reads, split-K)."""
+    ops = _ops()
+    torch.manual_seed(K + M + N)
+    A = torch.randn(K, M, device=DEV).bfloat16()
+    B = torch.randn(K, N, device=DEV).bfloat16()
+    assert ops.gemm_tn_supported(A, B)
+    ref = A.double().T @ B.double()
+    assert rel_err(ops.gemm_tn(A, B), ref) < 1e-5
+    assert rel_err(ops.gemm_tn(A, B, out_dtype=torch.bfloat16), ref) < 5e-3
+    C = torch.randn(M, N, device=DEV)
+    C0 = C.clone()
+    ops.gemm_tn(A, B, out=C, accumulate=True)
+    assert rel_err(C, C0.double() + ref) < 1e-5
+    C = torch.randn(M, N, device=DEV)
+    ops.gemm_tn(A, B, out=C, accumulate=False)
+    assert rel_err(C, ref) < 1e-5
+    # column slabs of wider matrices (packed activations)
+    wa = torch.randn(K, M + 64, device=DEV).bfloat16()
+    wb = torch.randn(K, N + 32, device=DEV).bfloat16()
+    assert rel_err(ops.gemm_tn(wa[:, 32:32 + M], wb[:, 8:8 + N]), wa[:, 32:32 + M].double().T @ wb[:, 8:8 + N].double()) < 1e-5
+    assert not ops.gemm_tn_supported(A[:31], B[:31])
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     from protein_lig_sedd_amd._lib import SeddError

@@ -25,3 +25,8 @@ for name, m, n, k, od, acc in shapes:
     print(f"{name:10s} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
 x = torch.randn(M, 3072, device="cuda").bfloat16()
 ms = timeit(lambda: ops.transpose(x)); print(f"transpose [{M},3072] bf16: {ms*1e3:.1f} us  {2*x.numel()*2/ms/1e6:.0f} GB/s")
+for name, m, n, k in (("fc1 wgrad TN", 3072, 768, M), ("fc2 wgrad TN", 768, 3072, M), ("qkv wgrad TN", 2304, 768, M), ("out wgrad TN", 768, 768, M)):
+    A = torch.randn(k, m, device="cuda").bfloat16(); B = torch.randn(k, n, device="cuda").bfloat16()
+    C = torch.zeros(m, n, device="cuda")
+    ms = timeit(lambda: ops.gemm_tn(A, B, out=C, accumulate=True))
+    print(f"{name:13s} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
