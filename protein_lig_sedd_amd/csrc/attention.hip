@@ -108,19 +108,37 @@ __device__ __forceinline__ void mma_tr(f32x4 (&accT)[D / 16], const T* X, const 
     }
 }
 
-// stage rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks
+// Staging of rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks, split
+// in two halves: stage_load puts the tile into registers, stage_store parks it in LDS.  The kernels issue the loads
+// of tile t+1 right after tile t has been parked, so the global-memory latency runs under tile t's MFMA / softmax work.
+template <typename T, int D> struct TileRegs {
+    static constexpr int EPC = 16 / sizeof(T);   // elements per chunk
+    static constexpr int CPR = D / EPC;          // chunks per row
+    static constexpr int NCH = TILE * CPR / 256; // chunks per thread (256 threads)
+    static_assert(TILE * CPR % 256 == 0, "tile chunks divide over the block");
+    uint4 v[NCH];
+};
 template <typename T, int D>
-__device__ __forceinline__ void stage_tile(T* lds, const T* g, int64_t ls, int r0, int nrows) {
-    constexpr int LS = D + Op<T>::PAD;
-    constexpr int EPC = 16 / sizeof(T);  // elements per chunk
-    constexpr int CPR = D / EPC;
-    for (int c = threadIdx.x; c < TILE * CPR; c += blockDim.x) {
-        const int row = c / CPR, cc = c % CPR;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (r0 + row < nrows) val = *reinterpret_cast<const uint4*>(g + (int64_t)(r0 + row) * ls + cc * EPC);
-        *reinterpret_cast<uint4*>(lds + row * LS + cc * EPC) = val;
+__device__ __forceinline__ void stage_load(TileRegs<T, D>& t, const T* g, int64_t ls, int r0, int nrows) {
+    using R = TileRegs<T, D>;
+#pragma unroll
+    for (int n = 0; n < R::NCH; ++n) {
+        const int c = threadIdx.x + 256 * n, row = c / R::CPR, cc = c % R::CPR;
+        t.v[n] = make_uint4(0, 0, 0, 0);
+        if (r0 + row < nrows) t.v[n] = *reinterpret_cast<const uint4*>(g + (int64_t)(r0 + row) * ls + cc * R::EPC);
     }
 }
+template <typename T, int D> __device__ __forceinline__ void stage_store(T* lds, const TileRegs<T, D>& t) {
+    using R = TileRegs<T, D>;
+    constexpr int LS = D + Op<T>::PAD;
+#pragma unroll
+    for (int n = 0; n < R::NCH; ++n) {
+        const int c = threadIdx.x + 256 * n, row = c / R::CPR, cc = c % R::CPR;
+        *reinterpret_cast<uint4*>(lds + row * LS + cc * R::EPC) = t.v[n];
+    }
+}
+// 2^x on the hardware unit (v_exp_f32); probabilities below the normal range flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <typename T> __device__ __forceinline__ void store4T(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4T<float>(float* p, f32x4 v) {
@@ -169,11 +187,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T, D> rk, rv;
+    stage_load<T, D>(rk, kb, sh.kv_ls, 0, sh.Lk);
+    stage_load<T, D>(rv, vb, sh.kv_ls, 0, sh.Lk);
     for (int k0 = 0; k0 < sh.Lk; k0 += TILE) {
         __syncthreads();
-        stage_tile<T, D>(Ks, kb, sh.kv_ls, k0, sh.Lk);
-        stage_tile<T, D>(Vs, vb, sh.kv_ls, k0, sh.Lk);
+        stage_store<T, D>(Ks, rk);
+        stage_store<T, D>(Vs, rv);
         __syncthreads();
+        if (k0 + TILE < sh.Lk) {
+            stage_load<T, D>(rk, kb, sh.kv_ls, k0 + TILE, sh.Lk);
+            stage_load<T, D>(rv, vb, sh.kv_ls, k0 + TILE, sh.Lk);
+        }
         f32x4 S[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -203,14 +228,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m[mt], mx);
             const float ms = mn == -INFINITY ? 0.f : mn;  // fully masked so far: keep everything at 0
-            const float alpha = exp2f(m[mt] - ms);
+            const float alpha = fast_exp2(m[mt] - ms);
             m[mt] = mn;
             float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(S[mt][t][r] - ms);
+                    const float p = fast_exp2(S[mt][t][r] - ms);
                     S[mt][t][r] = p;
                     rs += p;
                 }
@@ -305,11 +330,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T, D> rk, rv;
+    stage_load<T, D>(rk, kb, sh.kv_ls, 0, sh.Lk);
+    stage_load<T, D>(rv, vb, sh.kv_ls, 0, sh.Lk);
     for (int k0 = 0; k0 < sh.Lk; k0 += TILE) {
         __syncthreads();
-        stage_tile<T, D>(Ks, kb, sh.kv_ls, k0, sh.Lk);
-        stage_tile<T, D>(Vs, vb, sh.kv_ls, k0, sh.Lk);
+        stage_store<T, D>(Ks, rk);
+        stage_store<T, D>(Vs, rv);
         __syncthreads();
+        if (k0 + TILE < sh.Lk) {
+            stage_load<T, D>(rk, kb, sh.kv_ls, k0 + TILE, sh.Lk);
+            stage_load<T, D>(rv, vb, sh.kv_ls, k0 + TILE, sh.Lk);
+        }
         f32x4 S[2][4], dP[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -329,7 +361,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
                 const bool valid = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const float p = valid ? exp2f(S[mt][t][r] * sl2 - lq[mt]) : 0.f;
+                    const float p = valid ? fast_exp2(S[mt][t][r] * sl2 - lq[mt]) : 0.f;
                     S[mt][t][r] = p * (dP[mt][t][r] - dl[mt]) * sh.scale;  // dS^T
                 }
             }
@@ -382,17 +414,30 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) adk[mt][dt] = adv[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T, D> rq, rdo;
+    float r_lse = INFINITY, r_del = 0.f;  // +inf -> p = 0 for padded queries
+#define DKV_LOAD(q0_)                                                                            \
+    do {                                                                                         \
+        stage_load<T, D>(rq, qb, sh.q_ls, (q0_), sh.Lq);                                         \
+        stage_load<T, D>(rdo, dob, sh.o_ls, (q0_), sh.Lq);                                       \
+        if (threadIdx.x < TILE) {                                                                \
+            const int qi = (q0_) + threadIdx.x;                                                  \
+            const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (qi < sh.Lq ? qi : 0);          \
+            r_lse = qi < sh.Lq ? lse[si] * LOG2E : INFINITY;                                     \
+            r_del = qi < sh.Lq ? delta[si] : 0.f;                                                \
+        }                                                                                        \
+    } while (0)
+    DKV_LOAD(0);
     for (int q0 = 0; q0 < sh.Lq; q0 += TILE) {
         __syncthreads();
-        stage_tile<T, D>(Qs, qb, sh.q_ls, q0, sh.Lq);
-        stage_tile<T, D>(dOs, dob, sh.o_ls, q0, sh.Lq);
+        stage_store<T, D>(Qs, rq);
+        stage_store<T, D>(dOs, rdo);
         if (threadIdx.x < TILE) {
-            const int qi = q0 + threadIdx.x;
-            const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (qi < sh.Lq ? qi : 0);
-            lse_s[threadIdx.x] = qi < sh.Lq ? lse[si] * LOG2E : INFINITY;  // +inf -> p = 0 for padded queries
-            del_s[threadIdx.x] = qi < sh.Lq ? delta[si] : 0.f;
+            lse_s[threadIdx.x] = r_lse;
+            del_s[threadIdx.x] = r_del;
         }
         __syncthreads();
+        if (q0 + TILE < sh.Lq) DKV_LOAD(q0 + TILE);
         f32x4 S[2][4], dP[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -411,7 +456,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
                 const float lq = lse_s[16 * t + 4 * g + r], dl = del_s[16 * t + 4 * g + r];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const float p = kvalid[mt] ? exp2f(S[mt][t][r] * sl2 - lq) : 0.f;
+                    const float p = kvalid[mt] ? fast_exp2(S[mt][t][r] * sl2 - lq) : 0.f;
                     S[mt][t][r] = p;                                         // P
                     dP[mt][t][r] = p * (dP[mt][t][r] - dl) * sh.scale;        // dS
                 }
@@ -422,6 +467,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
             mma_tr<T, D>(adk[mt], Qs, dP[mt], lane);
         }
     }
+#undef DKV_LOAD
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
         if (krow[mt] < sh.Lk) {
