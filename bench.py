@@ -90,6 +90,42 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{n} train steps of the same model at batch {B} x L {L}, fp32, oracle/sedd_cpu.py + AdamW/EMA"}
 
 
+# average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
+# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r1b_pmc_hbm_traffic.csv
+GEMM_HBM_BYTES_PER_LAUNCH = 286.9e6
+
+
+def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
+    """the HBM-bound loss / sampling kernels at the BASELINE configs[4] per-GPU shard size (512 x 1024 rows, V = 26,
+    bf16 log-scores): algorithmic bytes / HIP-event time on the launch stream."""
+    from protein_lig_sedd_amd import ops, _lib as L_
+    V = graph.dim
+    M = B * L
+    x = torch.randint(0, V, (B, L), device=dev)
+    x[torch.rand(B, L, device=dev) < 0.5] = V - 1
+    x0 = torch.randint(0, V - 1, (B, L), device=dev)
+    logits = torch.randn(B, L, V, device=dev).to(torch.bfloat16)
+    u = torch.rand(B, L, V, device=dev)
+    sig = torch.rand(B, device=dev) + 0.1
+    out = {}
+    for name, nbytes, fn in (
+            ("predictor_step_analytic", M * (V * 2 + V * 4 + 16), lambda: ops.predictor_step(graph, L_.STEP_ANALYTIC, logits, x, sig, u)),
+            ("predictor_step_euler", M * (V * 2 + V * 4 + 16), lambda: ops.predictor_step(graph, L_.STEP_EULER, logits, x, sig, u)),
+            ("score_entropy_fwd_bwd", M * (2 * V * 2 + 20), lambda: ops.score_entropy_fwd(graph, logits, sig, x, x0, gw=sig))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / iters
+        out[name] = {"avg_us": us, "achieved_GBs": nbytes / us / 1e3, "frac_hbm_peak": nbytes / us / 1e3 / PEAK_HBM_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +194,9 @@ def main():
         sprof = ops.PROF.summary()
         ops.PROF = None
         n_l, ms_l, by_l = sprof.get("predictor_step", (0, 0.0, 0.0))
+        hbm = hbm_kernels_cfg5(graph, dev)
         samp = {"sampler_model_evals_per_s": world * (args.sample_steps + 1) / ds * B,
+                "hbm_kernels_at_cfg5_shard": hbm,
                 "seqs_per_s_at_1024_steps": world * B / (ds / (args.sample_steps + 1) * 1025),
                 "predictor_step": {"launches": n_l, "avg_us": 1e3 * ms_l / max(n_l, 1),
                                    "achieved_GBs": by_l / max(ms_l, 1e-9) / 1e6,
@@ -177,9 +215,14 @@ def main():
                                    "bf16, per-GPU batch %d, AdamW+EMA, dropout 0.1, dp%d" % (B, world),
                        "global_batch": B * world, "seq_len": L, "params": nparams, "parallelism": f"dp{world}"},
             "loss": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all Linear fwd/dgrad/wgrad launches)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "gemm_bf16_big_kernel NT/TN (+ gemm_bf16_nt_glds_kernel for small shapes): every "
+                                   "Linear fwd / dgrad / wgrad launch of the step",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches_per_step": n_g / max(args.steps, 1),
+                         "traffic": GEMM_HBM_BYTES_PER_LAUNCH if (B, L) == (64, 512) else None,
+                         "traffic_source": "profiles/r1b_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
+                                           "rocprofv3 --pmc passes of this command, average over the bf16 GEMM launches)",
+                         "launches_per_step": n_g / max(args.steps, 1),
                          "avg_launch_us": 1e3 * ms_g / max(n_g, 1),
                          "gemm_ms_per_step": ms_g / max(args.steps, 1)},
             "kernels": others,
