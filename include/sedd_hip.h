@@ -105,7 +105,8 @@ int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int
 int sedd_ln_modulate_fwd(const float* x, const float* w, const float* bias, const void* shift, const void* scale,
                          int mod_dtype, int64_t mod_stride, void* y, int out_dtype, float* mean, float* rstd,
                          int64_t M, int64_t L, int D, sedd_stream_t stream);
-/* backward: dx (fp32 [M,D]) is ACCUMULATED into (dx += ...) when accumulate != 0, else written.
+/* backward: dx (fp32 [M,D]) = dx_add + d(LN-modulate)/dx when dx_add != NULL (dx_add == dx accumulates in place;
+ * a different buffer adds the incoming residual-stream gradient without a copy), else just the LN term.
  * Partial column sums go to caller workspace ws fp32 [3, nchunk, D] (nchunk = sedd_ln_bwd_chunks(M, L)), in the
  * order d(w), d(shift)/d(bias), d(scale); chunks never straddle a batch element so that
  * sedd_ln_modulate_bwd_reduce can fold them into dw[D] (+=), dshift[B, .] and dscale[B, .] (fp32, written with
@@ -113,7 +114,7 @@ int sedd_ln_modulate_fwd(const float* x, const float* w, const float* bias, cons
 int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L);
 int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
                          int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
-                         int accumulate, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
+                         const float* dx_add, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
 int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float* dscale, int64_t dmod_stride,
                                 int64_t M, int64_t L, int D, sedd_stream_t stream);
 
@@ -168,6 +169,15 @@ int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n,
 int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
                  int64_t K, sedd_stream_t stream);
+/* Data gradient of Linear -> GELU(tanh) in one launch (autograd of the MLP nn.Sequential(Linear, GELU, Linear),
+ * transformer.py:129-133): C[M,N] = (A[M,K] * B[N,K]^T) .* gelu_tanh'(pre[M,N]) with A = dY of the second Linear,
+ * B = its weight transposed [in, out], pre = the saved pre-activation (row stride ldc, dtype of C); colsum (fp32 [N],
+ * may be NULL) receives += the column sums of C, i.e. the bias gradient of the first Linear.  bf16 only, M >= 192,
+ * N >= 96, N % 8 == 0, K % 32 == 0, 16-byte aligned C / pre rows; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then use
+ * sedd_gemm_nt + sedd_gelu_bwd + sedd_colsum). */
+int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                       int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
+                       sedd_stream_t stream);
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
  * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no

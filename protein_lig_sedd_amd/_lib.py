@@ -33,7 +33,7 @@ SIGNATURES = {
     "sedd_embedding_fwd": "pppliip",
     "sedd_embedding_bwd": "pppliip",
     "sedd_ln_modulate_fwd": "pppppilpippllip",
-    "sedd_ln_modulate_bwd": "pipppilpppipllip",
+    "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
     "sedd_gate_residual_fwd": "ppipilpfpllip",
     "sedd_gate_residual_bwd": "ppipilpfppllip",
@@ -48,6 +48,7 @@ SIGNATURES = {
     "sedd_cast": "pipilp",
     "sedd_gemm_nt": "plplpliipipilllp",
     "sedd_gemm_tn": "plplpliiilllplp",
+    "sedd_gemm_nt_dgelu": "plplpliipplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "i" + "f" + "lp",

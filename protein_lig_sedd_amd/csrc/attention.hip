@@ -206,24 +206,35 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) S[mt][t] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
         }
+        const bool plain = !mb && k0 + TILE <= sh.Lk;  // no key mask, no ragged tail: the cheap softmax path
         bool valid[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * t + 4 * g + r;
-                valid[t][r] = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
-            }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            float mx = -INFINITY;
+        if (!plain) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    S[mt][t][r] = valid[t][r] ? S[mt][t][r] * sl2 : -INFINITY;
-                    mx = fmaxf(mx, S[mt][t][r]);
+                    const int key = k0 + 16 * t + 4 * g + r;
+                    valid[t][r] = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
                 }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float mx = -INFINITY;
+            if (plain) {  // max on the raw scores (the scale is positive), scale folded into the exponent's fma
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[mt][t][r]);
+                mx *= sl2;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        S[mt][t][r] = valid[t][r] ? S[mt][t][r] : -INFINITY;
+                        mx = fmaxf(mx, S[mt][t][r] * sl2);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m[mt], mx);
@@ -235,7 +246,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(S[mt][t][r] - ms);
+                    const float p = fast_exp2(fmaf(S[mt][t][r], sl2, -ms));
                     S[mt][t][r] = p;
                     rs += p;
                 }

@@ -133,8 +133,8 @@ template <typename TD, typename TM, int NV>
 __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, const TM* __restrict__ scale,
                                                          int64_t mod_stride, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, float* __restrict__ dx,
-                                                         int accumulate, float* __restrict__ ws, int64_t nchunk,
+                                                         const float* __restrict__ rstd, float* dx,
+                                                         const float* dx_add, float* __restrict__ ws, int64_t nchunk,
                                                          int64_t L, int D) {
     __shared__ float red[3 * NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                 float4 o = make_float4(rs * (g[k].x - c1 - xh[k].x * c2), rs * (g[k].y - c1 - xh[k].y * c2),
                                        rs * (g[k].z - c1 - xh[k].z * c2), rs * (g[k].w - c1 - xh[k].w * c2));
                 float* dp = dx + row * D + c;
-                if (accumulate) {
-                    const float4 p = load4<float>(dp);
+                if (dx_add) {  // (dx_add may be dx itself: in-place accumulation)
+                    const float4 p = load4<float>(dx_add + row * D + c);
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 store4<float>(dp, o);
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
 
 extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
                                     int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd,
-                                    float* dx, int accumulate, float* ws, int64_t M, int64_t L, int D,
+                                    float* dx, const float* dx_add, float* ws, int64_t M, int64_t L, int D,
                                     sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(dy_dtype) && dt_ok(mod_dtype), "ln_modulate_bwd: bad dtype");
     SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "ln_modulate_bwd: bad sizes M=%ld L=%ld", (long)M, (long)L);
@@ -234,10 +234,10 @@ extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x
     DISPATCH_DT(dy_dtype, TD, DISPATCH_DT(mod_dtype, TM, {
         if (D <= 1024)
             hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 4>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, accumulate, ws, nchunk, L, D);
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D);
         else
             hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 8>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, accumulate, ws, nchunk, L, D);
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D);
     }));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;

@@ -33,6 +33,29 @@ __device__ __forceinline__ float gelu_tanh_f(float u) {
     return 0.5f * u * (1.0f + t);
 }
 
+// tanh on the hardware exp / rcp units: 1 - 2 / (1 + e^{2x}); absolute error ~1e-7, far inside bf16 rounding.  Used by
+// the bf16 epilogues only (libm's tanhf costs ~40 VALU instructions per element, which a one-block-per-CU GEMM
+// epilogue cannot hide); fp32 outputs keep tanhf.
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+template <typename TO> __device__ __forceinline__ float gelu_tanh_t(float u) {
+    const float a = 0.7978845608028654f * (u + 0.044715f * u * u * u);
+    const float t = sizeof(TO) == 2 ? tanh_fast(a) : tanhf(a);
+    return 0.5f * u * (1.0f + t);
+}
+template <typename TO> __device__ __forceinline__ float gelu_tanh_grad_t(float u) {
+    const float a = 0.7978845608028654f * (u + 0.044715f * u * u * u);
+    const float t = sizeof(TO) == 2 ? tanh_fast(a) : tanhf(a);
+    return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * u * u);
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float u) {
+    const float t = tanhf(0.7978845608028654f * (u + 0.044715f * u * u * u));
+    return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * u * u);
+}
+#define EPI_DGELU 3  // internal (sedd_gemm_nt_dgelu): C = (A B^T) * gelu_tanh'(pre), pre is an INPUT, column sums out
+
 // bijective XCD-aware remap (8 XCDs): blocks that share an XCD get a contiguous range of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
@@ -72,7 +95,7 @@ __device__ __forceinline__ void epilogue4(TO* __restrict__ C, int64_t ldc, TO* _
                 for (int r = 0; r < 4 && col + r < N; ++r) pp[r] = from_f32<TO>(v[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_t<TO>(v[r]);
     }
     if (accumulate) {
         if constexpr (sizeof(TO) == 4) {
@@ -285,14 +308,15 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 //   k-contiguous MFMA fragments come out of LDS through the transposing read ds_read_b64_tr_b16, which hands lane
 //   (g, i) the four rows 4g..4g+3 of column i: a fragment is two of them (rows 4g+j and 16+4g+j) — a permutation of the
 //   32 k values that both operands share, which a sum over k allows.
-template <typename TO, int BN_, int NST, bool TN>
+template <typename TO, int BN_, int NST, bool TN, bool DG>
 __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
                                                             TO* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int epi,
                                                             TO* __restrict__ pre, int accumulate, int64_t M,
                                                             int64_t N, int64_t Kper, int64_t Ktot, int ntn,
-                                                            int ntiles, int splitk, float4* __restrict__ slabs) {
+                                                            int ntiles, int splitk, float4* __restrict__ slabs,
+                                                            float* __restrict__ colsum) {
     constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
     constexpr int LA = 2, LB = BN_ / 128, LPT = LA + LB;              // DMA wave-instructions per stage
     constexpr int ASLOTS = BIG_BM * 4, SLOTS = (BIG_BM + BN_) * 4;    // 16-byte slots per stage
@@ -488,7 +512,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 bv[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (epi != SEDD_EPI_NONE) {
+                if (epi == SEDD_EPI_BIAS || epi == SEDD_EPI_BIAS_GELU) {
                     const int64_t c = col_w + n * 16 + 4 * (lane >> 4);
                     bv[n].x = c + 0 < N ? bias[c + 0] : 0.f;
                     bv[n].y = c + 1 < N ? bias[c + 1] : 0.f;
@@ -496,6 +520,67 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
                     bv[n].w = c + 3 < N ? bias[c + 3] : 0.f;
                 }
             }
+            if constexpr (DG) {
+                // data gradient through GELU: the pre-activation tile comes in with coalesced 16-byte loads (all
+                // passes up front, under the next tile's prologue), is re-read from the staging region in the MFMA
+                // layout, and the column sums of the result (the bias gradient of the Linear below) are reduced over
+                // the wave's rows and added to colsum with one atomic per column and wave
+                constexpr int RPI = 64 / SC::LPR;
+                const int rsub = lane / SC::LPR, chunk = lane % SC::LPR;
+                constexpr int PD = TM < 4 ? TM : 4;  // passes of pre-activation kept in flight
+                uint4 pr[PD][SC::RPP / RPI];
+#define DGELU_LOAD(pass_)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < SC::RPP / RPI; ++i) {                                                      \
+        const int64_t gr = row_t + (pass_) * 16 + i * RPI + rsub, gc = col_w + chunk * SC::EPC;                      \
+        pr[(pass_) % PD][i] = make_uint4(0, 0, 0, 0);                                                                \
+        if (gr < M && gc + SC::EPC <= N) pr[(pass_) % PD][i] = *reinterpret_cast<const uint4*>(pre + gr * ldc + gc); \
+    }
+#pragma unroll
+                for (int pass = 0; pass < PD; ++pass) DGELU_LOAD(pass)
+                f32x4 cs[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) cs[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pass = 0; pass < TM; ++pass) {
+#pragma unroll
+                    for (int i = 0; i < SC::RPP / RPI; ++i)
+                        *reinterpret_cast<uint4*>(reg + (i * RPI + rsub) * SC::PITCH + chunk * 16) = pr[pass % PD][i];
+                    if (pass + PD < TM) DGELU_LOAD(pass + PD)
+                    const bool rok = row_t + pass * 16 + (lane & 15) < M;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        union { uint2 u; TO e[4]; } pv;
+                        pv.u = *reinterpret_cast<const uint2*>(reg + (lane & 15) * SC::PITCH + (n * 16 + 4 * (lane >> 4)) * sizeof(TO));
+                        f32x4& v = acc[pass][n];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // the reference rounds the Linear's data gradient to the activation dtype before GELU's
+                            const float dy = to_f32<TO>(from_f32<TO>(v[r]));
+                            v[r] = to_f32<TO>(from_f32<TO>(dy * gelu_tanh_grad_t<TO>(to_f32<TO>(pv.e[r]))));
+                            cs[n][r] += rok ? v[r] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        stage_put4<TO>(reg, lane & 15, n * 16 + 4 * (lane >> 4), acc[pass][n]);
+                    stage_flush<TO>(reg, C, ldc, row_t + pass * 16, col_w, M, N, lane, 0);
+                }
+#undef DGELU_LOAD
+                if (colsum) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float t = cs[n][r];
+                            t += __shfl_xor(t, 1, 64);
+                            t += __shfl_xor(t, 2, 64);
+                            t += __shfl_xor(t, 4, 64);
+                            t += __shfl_xor(t, 8, 64);
+                            const int64_t c = col_w + n * 16 + 4 * (lane >> 4) + r;
+                            if ((lane & 15) == 0 && c < N) atomicAdd(colsum + c, t);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int pass = 0; pass < TM / FPP; ++pass) {
                 const int64_t row_w = row_t + pass * SC::RPP;
@@ -512,7 +597,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
                             v[3] = to_f32<TO>(from_f32<TO>(v[3] + bv[n].w));
                             if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), v);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_t<TO>(v[r]);
                         }
                     if (pre) stage_flush<TO>(reg, pre, ldc, row_w, col_w, M, N, lane, 0);
                 } else if (epi == SEDD_EPI_BIAS) {
@@ -530,6 +615,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
                     for (int n = 0; n < 4; ++n)
                         stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), acc[pass * FPP + mm][n]);
                 stage_flush<TO>(reg, C, ldc, row_w, col_w, M, N, lane, 0);
+            }
             }
         }
         if (next >= ntiles) break;
@@ -742,14 +828,14 @@ static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
     *kper = per * BIG_BK;
 }
 
-extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                            int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
-                            int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                        int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
+                        int64_t K, float* colsum, sedd_stream_t stream) {
     SEDD_CHECK_ARG((in_dtype == SEDD_F32 || in_dtype == SEDD_BF16) && (out_dtype == SEDD_F32 || out_dtype == SEDD_BF16),
                    "gemm_nt: bad dtype");
-    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU, "gemm_nt: bad epilogue %d", epilogue);
+    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= EPI_DGELU, "gemm_nt: bad epilogue %d", epilogue);
     SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_nt: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || bias, "gemm_nt: epilogue needs a bias");
+    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == EPI_DGELU || bias, "gemm_nt: epilogue needs a bias");
     SEDD_CHECK_ARG(!accumulate || epilogue == SEDD_EPI_NONE, "gemm_nt: accumulate only with SEDD_EPI_NONE");
     const int kal = in_dtype == SEDD_BF16 ? 8 : 4;
     if (K % kal || lda % kal || ldb % kal || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || lda < K || ldb < K || ldc < N) {
@@ -765,12 +851,23 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == SEDD_BF16) {
         // big-tile path: 256 x 256 or 256 x 128 tiles, whichever quantises better onto the 256 CUs
-        if (K % BIG_BK == 0 && M >= 192 && N >= 96 && !getenv("SEDD_GEMM_SMALL_TILES")) {
+        const bool big_ok = K % BIG_BK == 0 && M >= 192 && N >= 96 && !getenv("SEDD_GEMM_SMALL_TILES");
+        if (epilogue == EPI_DGELU) {
+            // only the big-tile kernel's staged bf16 epilogue implements it
+            if (!big_ok || out_dtype != SEDD_BF16 || accumulate || (ldc * 2) % 16 || ((uintptr_t)C & 15) ||
+                ((uintptr_t)pre & 15) || N % 8) {
+                sedd_set_error("gemm_nt_dgelu: unsupported shape/alignment (bf16, M >= 192, N >= 96, N %% 8 == 0, "
+                               "K %% 32 == 0, 16-byte aligned C / pre rows)");
+                return SEDD_ERR_UNSUPPORTED_SHAPE;
+            }
+        }
+        if (big_ok) {
             const int64_t tm = (M + BIG_BM - 1) / BIG_BM;
             const int64_t t256 = tm * ((N + 255) / 256), t128 = tm * ((N + 127) / 128);
             // cost ~ (number of chip-wide rounds) x (tile work); the 256-wide tile does twice the work per round
             const double c256 = (double)((t256 + 255) / 256) * 2.0, c128 = (double)((t128 + 255) / 256) * 1.05;
-            const bool wide = N > 128 && c256 <= c128;
+            // (the 256-wide instantiation of the dGELU epilogue spills; the 128-wide one does not)
+            const bool wide = N > 128 && c256 <= c128 && epilogue != EPI_DGELU;
             const int bn = wide ? 256 : 128;
             const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
             int64_t kper = K;
@@ -780,10 +877,15 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
             // one persistent block per CU (the operand ring takes most of a CU's LDS)
             const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \
-                       (int)tn, (int)tiles, splitk, (float4*)nullptr)
-            if (out_dtype == SEDD_BF16) {
+                       (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum)
+            if (epilogue == EPI_DGELU) {
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, true>), g2, dim3(512), 0, st,
+                                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
+                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
+                                       (float4*)nullptr, colsum);
+            } else if (out_dtype == SEDD_BF16) {
                 if (wide) BIG_LAUNCH(bf16_t, 256, 4);
                 else BIG_LAUNCH(bf16_t, 128, 4);
             } else {
@@ -829,6 +931,24 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
     return SEDD_OK;
 }
 
+extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                            int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
+                            int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU, "gemm_nt: bad epilogue %d", epilogue);
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, pre, accumulate, M, N, K, nullptr,
+                        stream);
+}
+
+// C[M,N] = (A[M,K] * B[N,K]^T) .* gelu_tanh'(pre[M,N]); colsum[N] += column sums of C (optional).  The data gradient of
+// Linear -> GELU in one launch (autograd of nn.Sequential(Linear, GELU(tanh), Linear), transformer.py:129-133).
+extern "C" int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                  int in_dtype, int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N,
+                                  int64_t K, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(pre, "gemm_nt_dgelu: pre is null");
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
+                        K, colsum, stream);
+}
+
 // C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations
 // (dW[out,in] = dY[tokens,out]^T X[tokens,in]), no transposed copies.  bf16 operands, fp32 or bf16 C.
 extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
@@ -868,9 +988,9 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     }
     const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
 #define TN_LAUNCH(TO, BN_)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs)
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, (float*)nullptr)
     if (out_dtype == SEDD_BF16) {
         if (wide) TN_LAUNCH(bf16_t, 256);
         else TN_LAUNCH(bf16_t, 128);

@@ -97,6 +97,27 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
     return dx, dW, db
 
 
+def mlp_out_bwd(g2d, u2d, dy2d, W2, b2, b1):
+    """backward of `y = Linear2(GELU(u))` down to du: -> (du, dW2, db2, db1).  The data gradient, GELU's derivative and
+    the first Linear's bias gradient (column sums of du) are one GEMM launch when the shapes allow."""
+    W2t = compute_weight(W2, dy2d.dtype, transposed=True)
+    if W2t.shape[1] == dy2d.shape[1] and ops.gemm_nt_dgelu_supported(dy2d, W2t, u2d):
+        _, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2, need_dx=False)
+        bs = _sink(b1)
+        db1 = None
+        if bs is None:
+            bs = db1 = torch.zeros(u2d.shape[1], dtype=torch.float32, device=u2d.device)
+        du = ops.gemm_nt_dgelu(dy2d, W2t, u2d, colsum=bs)
+        return du, dW2, db2, db1
+    dg, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2)
+    du = ops.gelu_bwd(u2d, dg)
+    bs = _sink(b1)
+    if bs is not None:
+        ops.colsum(du, out=bs, accumulate=True)
+        return du, dW2, db2, None
+    return du, dW2, db2, ops.colsum(du)
+
+
 def _vec_sink(param, D):
     s = _sink(param)
     if s is not None:
@@ -161,15 +182,15 @@ def ddit_block_backward(dx2, st, P, n_heads):
     mod, cdt = st["mod"], st["h1"].dtype
     grads = {}
     dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
-    dx = dx2.clone()
+    dx = torch.empty_like(dx2)  # = dx2 + both LN-branch gradients (dx2 itself is autograd's and stays untouched)
     # ---- MLP branch: x2 = x1 + gate_mlp * dropout(mlp(modulate(LN(x1))))
-    dy = ops.gate_residual_bwd(dx, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
-    dg, grads["mlp.2.weight"], grads["mlp.2.bias"] = linear_bwd(st["g"], dy, P["mlp.2.weight"], P["mlp.2.bias"])
-    du = ops.gelu_bwd(st["u"], dg)
-    dh2, grads["mlp.0.weight"], grads["mlp.0.bias"] = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], P["mlp.0.bias"])
+    dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
+    du, grads["mlp.2.weight"], grads["mlp.2.bias"], grads["mlp.0.bias"] = mlp_out_bwd(
+        st["g"], st["u"], dy, P["mlp.2.weight"], P["mlp.2.bias"], P["mlp.0.bias"])
+    dh2, grads["mlp.0.weight"], _ = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], None)
     dw2, grads["norm2.weight"] = _vec_sink(P["norm2.weight"], D)
     ops.ln_modulate_bwd(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],
-                        st["rstd2"], dx, True, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
+                        st["rstd2"], dx, dx2, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
     # ---- attention branch: x1 = x + gate_msa * dropout(attn_out(attn(rotary(qkv(modulate(LN(x)))))))
     da = ops.gate_residual_bwd(dx, st["a"], mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], st["keep1"], st["inv"]).view(M, D)
     do, grads["attn_out.weight"], _ = linear_bwd(st["o"].view(M, D), da, P["attn_out.weight"])

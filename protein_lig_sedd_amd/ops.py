@@ -256,15 +256,19 @@ def ln_modulate_fwd(x, w, shift=None, scale=None, bias=None, out_dtype=torch.flo
 
 
 def ln_modulate_bwd(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dscale):
-    """dx fp32 [B,L,D] written or accumulated; dw fp32 [D] accumulated (+=); dshift/dscale fp32 [B, D] (strided)
-    views written (may be None)."""
+    """dx fp32 [B,L,D] = LN-modulate gradient (+ accumulate): accumulate False -> written, True -> dx += (in place),
+    a tensor -> dx = accumulate + gradient (no copy of the incoming residual gradient needed);
+    dw fp32 [D] accumulated (+=); dshift/dscale fp32 [B, D] (strided) views written (may be None)."""
+    add = dx if accumulate is True else (None if (accumulate is False or accumulate is None) else accumulate)
+    if add is not None and (add.shape != dx.shape or add.dtype != torch.float32 or not add.is_contiguous()):
+        raise ValueError("ln_modulate_bwd: addend must be a contiguous fp32 tensor of dx's shape")
     B, L, D = x.shape
     M = B * L
     nchunk = lib().sedd_ln_bwd_chunks(M, L)
     ws = torch.empty(3 * nchunk * D, dtype=torch.float32, device=x.device)
     sc, mdt, ms = _mod_args(scale)
     check(lib().sedd_ln_modulate_bwd(_p(dy), _dt(dy), _p(x), _p(w), _p(sc), mdt, ms, _p(mean), _p(rstd), _p(dx),
-                                     1 if accumulate else 0, _p(ws), M, L, D, _stream()), "sedd_ln_modulate_bwd")
+                                     _p(add), _p(ws), M, L, D, _stream()), "sedd_ln_modulate_bwd")
     dstride = dshift.stride(0) if dshift is not None else (dscale.stride(0) if dscale is not None else D)
     check(lib().sedd_ln_modulate_bwd_reduce(_p(ws), _p(dw), _p(dshift), _p(dscale), dstride, M, L, D, _stream()),
           "sedd_ln_modulate_bwd_reduce")
@@ -377,6 +381,28 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
         check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                  _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
     return (out, pre) if (gelu and want_pre) else out
+
+
+def gemm_nt_dgelu_supported(A, B, pre):
+    M, K = A.shape
+    N = B.shape[0]
+    return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and pre.dtype == torch.bfloat16 and M >= 192
+            and N >= 96 and N % 8 == 0 and K % 32 == 0 and pre.is_contiguous() and pre.data_ptr() % 16 == 0
+            and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nt_dgelu(A, B, pre, colsum=None):
+    """C = (A[M,K] @ B[N,K]^T) * gelu_tanh'(pre[M,N]) (bf16); colsum fp32 [N] += C.sum(0) when given."""
+    M, K = A.shape
+    N = B.shape[0]
+    if pre.shape != (M, N) or B.shape[1] != K:
+        raise ValueError(f"gemm_nt_dgelu: A {tuple(A.shape)} B {tuple(B.shape)} pre {tuple(pre.shape)}")
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_nt_dgelu(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                       _p(pre), _p(colsum), M, N, K, _stream()), "sedd_gemm_nt_dgelu")
+    return out
 
 
 def gemm_tn_supported(A, B):

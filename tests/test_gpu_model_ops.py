@@ -91,6 +91,25 @@ def test_gemm_tn_bf16(K, M, N):
     assert not ops.gemm_tn_supported(A[:31], B[:31])
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 3072, 768), (300, 200, 96)])
+def test_gemm_nt_dgelu(M, N, K):
+    """fused data gradient through GELU + bias-gradient column sums == gemm -> gelu_bwd -> colsum."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    A = (0.3 * torch.randn(M, K, device=DEV)).bfloat16()
+    B = (0.3 * torch.randn(N, K, device=DEV)).bfloat16()
+    pre = torch.randn(M, N, device=DEV).bfloat16()
+    assert ops.gemm_nt_dgelu_supported(A, B, pre)
+    cs = torch.ones(N, device=DEV)
+    out = ops.gemm_nt_dgelu(A, B, pre, colsum=cs)
+    ref = ops.gelu_bwd(pre, ops.gemm_nt(A, B))
+    assert rel_err(out.float(), ref.float()) < 2e-3  # (hardware-exp tanh in the epilogue vs tanhf: bf16 rounding flips)
+    assert rel_err(cs, 1 + ref.float().sum(0)) < 1e-4
+    pf = pre.float().requires_grad_(True)
+    F.gelu(pf, approximate="tanh").backward((A.double() @ B.double().T).float())
+    assert rel_err(out.float(), pf.grad) < 1e-2
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     from protein_lig_sedd_amd._lib import SeddError
