@@ -659,13 +659,32 @@ def g14_ema():
     save("g14_ema", **out)
 
 
+def g15_lr_schedule():
+    """utils/lr_scheduler.py:51-87 WarmupCosineLR stepped through warm-up, decay and past max_steps."""
+    from protlig_dd.utils.lr_scheduler import WarmupCosineLR
+    out = {}
+    for tag, kw in (("a", dict(warmup_steps=10, max_steps=50, base_lr=1e-5, max_lr=1e-3, min_lr=1e-6)),
+                    ("b", dict(warmup_steps=0, max_steps=7, base_lr=3e-4, max_lr=3e-4, min_lr=0.0))):
+        lin = torch.nn.Linear(2, 2)
+        opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+        sch = WarmupCosineLR(opt, **kw)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(kw["max_steps"] + 5):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        out[tag + "_lrs"] = np.array(lrs, dtype=np.float64)
+        out[tag + "_cfg"] = np.array([kw["warmup_steps"], kw["max_steps"], kw["base_lr"], kw["max_lr"], kw["min_lr"]], dtype=np.float64)
+    save("g15_lr_schedule", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for fn in (g1_noise, g2_sample_transition, g3_score_entropy, g4_graph_ops, g5_sample_categorical,
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
-               g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema):
+               g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

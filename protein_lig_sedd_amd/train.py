@@ -88,12 +88,15 @@ class SEDDTrainer:
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
-                 process_group=None, overlap=True):
+                 process_group=None, overlap=True, lr_schedule=None):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
         self.warmup, self.grad_clip = g("warmup", 0), g("grad_clip", 1.0)
         self.model, self.noise, self.graph = model, noise, graph
+        # optional step -> lr callable (e.g. lr_scheduler.warmup_cosine_lr of the cross-attention trainer,
+        # run_train_protlig_cross_att.py); default = losses.py:58-62 linear warm-up
+        self.lr_schedule = lr_schedule
         self.pg = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         cdt = getattr(model, "compute_dtype", torch.float32)
@@ -148,6 +151,9 @@ class SEDDTrainer:
         self.flat.refresh_compute_weights()
 
     def current_lr(self, step):
+        sched = getattr(self, "lr_schedule", None)
+        if sched is not None:
+            return float(sched(step))
         return self.lr * min(step / self.warmup, 1.0) if self.warmup and self.warmup > 0 else self.lr
 
     def train_step(self, batch, t=None, perturbed_batch=None, u=None):
@@ -210,22 +216,85 @@ class SEDDTrainer:
             loss /= self.world
         return loss
 
-    # ---- checkpoint in the reference's layout (utils/utils.py:87-95: optimizer / model / ema / step) ------------
+    # ---- checkpoint in the reference's layout (utils/utils.py:73-95: optimizer / model / ema / step) -------------
+    def optimizer_state_dict(self):
+        """torch.optim.Adam/AdamW `state_dict()` layout (what utils/utils.py:88 stores and :80 loads): per-parameter
+        `step` / `exp_avg` / `exp_avg_sq` in `model.parameters()` order, views of the flat moment buffers."""
+        fl = self.flat
+        step = torch.tensor(float(self.step_count))
+        state = {i: {"step": step.clone(), "exp_avg": fl.view(fl.m, i), "exp_avg_sq": fl.view(fl.v, i)}
+                 for i in range(len(fl.params))} if self.step_count > 0 else {}
+        group = {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(fl.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """accepts the reference's torch-optimizer layout (extra trailing parameters, e.g. the noise schedule's dummy
+        parameter of losses.py:35-46, are ignored) or this trainer's compact {"m", "v", "step"}."""
+        fl = self.flat
+        if "state" in sd:
+            steps = []
+            for i in range(len(fl.params)):
+                ent = sd["state"].get(i)
+                if ent is None:
+                    fl.view(fl.m, i).zero_()
+                    fl.view(fl.v, i).zero_()
+                    continue
+                fl.view(fl.m, i).copy_(ent["exp_avg"])
+                fl.view(fl.v, i).copy_(ent["exp_avg_sq"])
+                steps.append(int(ent["step"]))
+            return max(steps) if steps else 0
+        fl.m.copy_(sd["m"])
+        fl.v.copy_(sd["v"])
+        return int(sd["step"])
+
     def state_dict(self):
-        return {"optimizer": {"m": self.flat.m, "v": self.flat.v, "step": self.step_count},
-                "model": self.model.state_dict(), "ema": self.ema.state_dict(), "step": self.step_count}
+        return {"optimizer": self.optimizer_state_dict(), "model": self.model.state_dict(),
+                "ema": self.ema.state_dict(), "step": self.step_count}
 
     def load_state_dict(self, sd):
-        self.model.load_state_dict(sd["model"])
-        self.flat.m.copy_(sd["optimizer"]["m"])
-        self.flat.v.copy_(sd["optimizer"]["v"])
-        self.step_count = int(sd["step"])
+        model_sd = sd["model"]
+        if any(k.startswith("module.") for k in model_sd):  # DDP prefix (test/old_model/load_model_from_ckpt.py:57-62)
+            model_sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in model_sd.items()}
+        self.model.load_state_dict(model_sd)
+        opt_step = self.load_optimizer_state_dict(sd["optimizer"])
+        self.step_count = int(sd.get("step", opt_step))
         for dst, src in zip(self.flat.ema_params(), sd["ema"]["shadow_params"]):
             dst.copy_(src)
         self.ema.num_updates = sd["ema"]["num_updates"]
         if self.flat.pc is not None:
             ops.cast(self.flat.p, torch.bfloat16, out=self.flat.pc)
         self.flat.refresh_compute_weights()
+
+
+def save_checkpoint(ckpt_dir, state):
+    """utils/utils.py:85-95: `state` is either the reference's dict of objects (optimizer / model / ema / step) or a
+    SEDDTrainer; the file layout is the reference's either way."""
+    if isinstance(state, SEDDTrainer):
+        saved = state.state_dict()
+    else:
+        saved = {"optimizer": state["optimizer"].state_dict(), "model": state["model"].state_dict(),
+                 "ema": state["ema"].state_dict(), "step": state["step"]}
+    torch.save(saved, ckpt_dir)
+
+
+def restore_checkpoint(ckpt_dir, state, device):
+    """utils/utils.py:73-83 (returns `state` unchanged with a warning when the file is missing).  Files this package
+    wrote hold tensors, numbers and dicts only and load with weights_only=True."""
+    if not os.path.exists(ckpt_dir):
+        os.makedirs(os.path.dirname(ckpt_dir) or ".", exist_ok=True)
+        import logging
+        logging.warning(f"No checkpoint found at {ckpt_dir}. Returned the same state as input")
+        return state
+    loaded = torch.load(ckpt_dir, map_location=device, weights_only=True)
+    if isinstance(state, SEDDTrainer):
+        state.load_state_dict(loaded)
+        return state
+    state["optimizer"].load_state_dict(loaded["optimizer"])
+    state["ema"].load_state_dict(loaded["ema"])
+    state["step"] = loaded["step"]
+    return state
 
 
 def shard_batch(batch, rank, world):
