@@ -678,13 +678,73 @@ def g15_lr_schedule():
     save("g15_lr_schedule", **out)
 
 
+def g16_cross_train_trajectory():
+    """run_train_protlig_cross_att.py:244-333 — `calc_loss` + `train_step` followed line by line on the reference's
+    model / graphs / noise / EMA / WarmupCosineLR (the Trainer class itself imports wandb and the dataset stack, so its
+    step is replayed here): joint task, quirks as written (Q2: optimizer stepped twice per iteration, Q3: joint loss
+    = mean(dsigma) * (mean(SE_prot) + mean(SE_lig)) / 2), GradScaler omitted (fp32: scale 1), dropout 0."""
+    from protlig_dd.utils.lr_scheduler import WarmupCosineLR
+    torch.manual_seed(116)
+    cfg = cross_config(64, 2, 32, 2)
+    model = ref_cross.ProteinLigandDiffusionModel(cfg)
+    load_seeded(model, seed=16, std=0.05)
+    model.train()
+    gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    opt = torch.optim.AdamW(list(model.parameters()) + list(noise.parameters()), lr=3e-4, betas=(0.9, 0.999),
+                            eps=1e-8, weight_decay=0.01)
+    sched = WarmupCosineLR(opt, warmup_steps=2, max_steps=10, base_lr=1e-5, max_lr=1e-3, min_lr=1e-6)
+    B, Lp, Ll, iters = 3, 24, 16, 3
+    out = {"cfg": np.array([64, 2, 32, 2]), "hyper": np.array([0.9, 0.999, 1e-8, 0.01, 1.0, 0.999, 2, 10, 1e-5, 1e-3, 1e-6])}
+    ls, lps, lls, lrs = [], [], [], []
+    for it in range(iters):
+        g = torch.Generator().manual_seed(1600 + it)
+        p0 = torch.randint(0, 33, (B, Lp), generator=g)
+        l0 = torch.randint(0, 2362, (B, Ll), generator=g)
+        t = (1 - 1e-3) * torch.rand(B, generator=g) + 1e-3
+        up, ul = torch.rand(B, Lp, generator=g), torch.rand(B, Ll, generator=g)
+        sigma, dsigma = noise(t)
+        move = 1 - (-sigma[:, None]).exp()
+        pt = torch.where(up < move, torch.full_like(p0, 36), p0)   # graph.sample_transition with recorded uniforms
+        lt = torch.where(ul < move, torch.full_like(l0, 2364), l0)
+        out[f"p0_{it}"], out[f"l0_{it}"], out[f"t_{it}"], out[f"pt_{it}"], out[f"lt_{it}"] = p0, l0, t, pt, lt
+        lrs.append(opt.param_groups[0]["lr"])
+        log_score = model(protein_indices=pt, ligand_indices=lt, timesteps=sigma.reshape(-1), mode="joint")
+        loss_prot = gp.score_entropy(log_score[0], sigma[:, None], pt, p0).mean()
+        loss_lig = gl.score_entropy(log_score[1], sigma[:, None], lt, l0).mean()
+        loss = (loss_prot + loss_lig) / 2
+        loss = (dsigma[:, None] * loss).mean()
+        loss_prot = (dsigma[:, None] * loss_prot).mean()
+        loss_lig = (dsigma[:, None] * loss_lig).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)   # optimize_fn :244-249
+        opt.step()                                                 # scaler.step(optimizer)
+        ema.update(model.parameters())                             # :324
+        opt.step()                                                 # :325 (Q2)
+        opt.zero_grad()
+        sched.step()
+        ls.append(loss.detach()); lps.append(loss_prot.detach()); lls.append(loss_lig.detach())
+    out["losses"], out["losses_prot"], out["losses_lig"] = torch.stack(ls), torch.stack(lps), torch.stack(lls)
+    out["lrs"] = np.array(lrs, dtype=np.float64)
+    sd = model.state_dict()
+    names = [n for n, _ in model.named_parameters()]
+    for key in ("transformer.blocks_prot.0.attn_qkv.weight", "transformer.blocks_lig.1.mlp.2.bias",
+                "transformer.ligand_output.linear.weight", "transformer.protein_embed.embedding.weight"):
+        out["final." + key] = sd[key]
+        out["ema." + key] = ema.shadow_params[names.index(key)]
+    out["ema_num_updates"] = np.array(ema.num_updates)
+    save("g16_cross_train_trajectory", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for fn in (g1_noise, g2_sample_transition, g3_score_entropy, g4_graph_ops, g5_sample_categorical,
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
-               g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule):
+               g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule,
+               g16_cross_train_trajectory):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

@@ -312,3 +312,103 @@ def sharded_sampling(sampler, model, rank, world, gather=True, **kw):
     out = [torch.empty_like(x) for _ in range(world)]
     dist.all_gather(out, x)
     return torch.cat(out, 0)
+
+
+class CrossAttTrainer(SEDDTrainer):
+    """Training step of the dual-track cross-attention trainer (training/run_train_protlig_cross_att.py:192-333) on the
+    flat-buffer / fused-optimiser machinery: `calc_loss(batch, task)` and `train_step(batch, task)` with the
+    reference's quirks reproduced by default and switchable:
+
+      * double_step=True  (Q2): the optimiser advances twice per iteration on the same clipped gradients
+        (`scaler.step(optimizer)` in optimize_fn :247, then `optimizer.step()` :325); EMA is updated between the two;
+      * per_sample_weighting=False (Q3): joint loss = mean(dsigma) * (mean(SE_prot) + mean(SE_lig)) / 2 (:289-294);
+        True gives the per-sample weighting of processing/losses.py:29;
+      * task freezing (:192-216): `protein_only` / `protein_given_ligand` freeze every parameter whose name contains
+        'lig', `ligand_only` / `ligand_given_protein` those containing 'prot' — done before the flat buffers are built.
+
+    batch: dict with int64 'prot_tokens' [B, Lp] and/or 'lig_tokens' [B, Ll].  The `*_given_*` tasks of the reference
+    trainer pass raw sequence strings to the ESM / MolFormer encoders (network downloads) and are out of scope."""
+
+    def __init__(self, model, noise, graph_prot, graph_lig, optim, task="joint", ema_decay=0.9999, sampling_eps=1e-3,
+                 world_size=None, process_group=None, lr_schedule=None, double_step=True, per_sample_weighting=False):
+        if task in ("protein_given_ligand", "protein_only"):
+            self.freeze_model(model, "lig")
+        elif task in ("ligand_given_protein", "ligand_only"):
+            self.freeze_model(model, "prot")
+        super().__init__(model, noise, graph_prot, optim, ema_decay=ema_decay, sampling_eps=sampling_eps,
+                         world_size=world_size, process_group=process_group, overlap=False, lr_schedule=lr_schedule)
+        self.graph_prot, self.graph_lig = graph_prot, graph_lig
+        self.task, self.double_step, self.per_sample_weighting = task, double_step, per_sample_weighting
+        self.sampling_eps = sampling_eps
+        self.opt_steps = 0  # Adam's own step counter (advances twice per iteration with double_step)
+
+    @staticmethod
+    def freeze_model(model, freeze_what):
+        for name, param in model.named_parameters():
+            if freeze_what in name:
+                param.requires_grad = False
+        return model
+
+    def calc_loss(self, batch, task, t=None, perturbed=None):
+        """-> loss [B, 1] (single-track tasks) or (loss, loss_prot, loss_lig) for 'joint' (:250-297).
+        perturbed: optional dict of pre-corrupted 'prot_tokens' / 'lig_tokens' (bit-exact replay of a noise draw)."""
+        perturbed = perturbed or {}
+        first = batch["prot_tokens"] if "prot_tokens" in batch else batch["lig_tokens"]
+        dev = first.device
+        if t is None:
+            t = (1 - self.sampling_eps) * torch.rand(first.shape[0], device=dev) + self.sampling_eps
+        sigma, dsigma = self.noise(t)
+        sig = sigma.reshape(-1)
+
+        def corrupt(key, graph):
+            return perturbed[key] if key in perturbed else graph.sample_transition(batch[key], sigma[:, None])
+
+        if task == "protein_only":
+            pi = corrupt("prot_tokens", self.graph_prot)
+            ls = self.model(protein_indices=pi, timesteps=sig, mode=task)
+            return dsigma[:, None] * self.graph_prot.score_entropy(ls, sigma[:, None], pi, batch["prot_tokens"])
+        if task == "ligand_only":
+            li = corrupt("lig_tokens", self.graph_lig)
+            ls = self.model(ligand_indices=li, timesteps=sig, mode=task)
+            return dsigma[:, None] * self.graph_lig.score_entropy(ls, sigma[:, None], li, batch["lig_tokens"])
+        if task == "joint":
+            pi, li = corrupt("prot_tokens", self.graph_prot), corrupt("lig_tokens", self.graph_lig)
+            lp, ll = self.model(protein_indices=pi, ligand_indices=li, timesteps=sig, mode=task)
+            se_p = self.graph_prot.score_entropy(lp, sigma[:, None], pi, batch["prot_tokens"])
+            se_l = self.graph_lig.score_entropy(ll, sigma[:, None], li, batch["lig_tokens"])
+            if self.per_sample_weighting:
+                lp_, ll_ = (dsigma[:, None] * se_p).mean(-1, keepdim=True), (dsigma[:, None] * se_l).mean(-1, keepdim=True)
+                return (lp_ + ll_) / 2, lp_, ll_
+            mp, ml = se_p.mean(), se_l.mean()
+            return dsigma[:, None] * ((mp + ml) / 2), dsigma[:, None] * mp, dsigma[:, None] * ml
+        raise NotImplementedError(f"Task {task} not implemented")
+
+    def train_step(self, batch, task=None, t=None, perturbed=None):
+        """:299-333.  Returns loss (or (loss, loss_prot, loss_lig) for 'joint') as 0-dim device tensors."""
+        task = task or self.task
+        fl = self.flat
+        fl.g.zero_()
+        self.model.train()
+        out = self.calc_loss(batch, task, t=t, perturbed=perturbed)
+        loss = out[0].mean() if task == "joint" else out.mean()
+        loss.backward()
+        if self.world > 1:
+            dist.all_reduce(fl.g, group=self.pg)
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        ops.sumsq_clip(fl.g, gscale, self.grad_clip if self.grad_clip is not None else -1.0, self._ws, self._norm)
+        clip = self._norm[1:] if (self.grad_clip is not None and self.grad_clip >= 0) else None
+        lr = self.current_lr(self.step_count - 1) if self.lr_schedule is not None else self.current_lr(self.step_count)
+        self.ema.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
+        self.opt_steps += 1
+        ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
+                           self.wd, self.opt_steps, decay)
+        if self.double_step:  # Q2: the same clipped gradients once more; EMA already took the first step's weights
+            self.opt_steps += 1
+            ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
+                               self.eps, self.wd, self.opt_steps, 1.0)
+        fl.refresh_compute_weights()
+        if task == "joint":
+            return loss.detach(), out[1].mean().detach(), out[2].mean().detach()
+        return loss.detach()

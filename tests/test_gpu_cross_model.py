@@ -131,3 +131,56 @@ def test_cross_model_sampler_and_bf16():
     samp = sampling.get_pc_sampler(graph_lib.Absorbing(36), noise, (B, Lp), "analytic", 4, device=DEV)
     out = samp(m32, task="protein_only")
     assert out.shape == (B, Lp) and int(((out < 0) | (out >= 36)).sum()) == 0
+
+
+def test_g16_cross_trainer_trajectory(golden):
+    """CrossAttTrainer (joint task, quirks Q2 + Q3 as written, WarmupCosineLR) vs the 3-iteration trajectory replayed
+    on the reference's model / graphs / EMA / scheduler (golden g16): losses, final weights, EMA."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.lr_scheduler import warmup_cosine_lr
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd.train import CrossAttTrainer
+    g = golden("g16_cross_train_trajectory")
+    D, H, C, nb = g["cfg"].tolist()
+    b1, b2, eps, wd, clip, decay, wu, ms, blr, mlr, nlr = g["hyper"].tolist()
+    model = ProteinLigandDiffusionModel(_cfg(D, H, C, nb)).to(DEV)
+    load_sd(model, seeded_state_dict(cross_shapes(D, C, nb), seed=16, std=0.05))
+    tr = CrossAttTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(DEV), graph_lib.Absorbing(36), graph_lib.Absorbing(2364),
+                         dict(lr=3e-4, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, warmup=0, grad_clip=clip),
+                         task="joint", ema_decay=decay, world_size=1,
+                         lr_schedule=lambda s: warmup_cosine_lr(s, int(wu), int(ms), blr, mlr, nlr))
+    for it in range(3):
+        batch = {"prot_tokens": g[f"p0_{it}"].to(DEV), "lig_tokens": g[f"l0_{it}"].to(DEV)}
+        pert = {"prot_tokens": g[f"pt_{it}"].to(DEV), "lig_tokens": g[f"lt_{it}"].to(DEV)}
+        assert tr.current_lr(tr.step_count) == pytest.approx(float(g["lrs"][it]), rel=1e-12)
+        loss, lp, ll = tr.train_step(batch, "joint", t=g[f"t_{it}"].to(DEV), perturbed=pert)
+        assert_close(loss, g["losses"][it], 5e-4, 0, f"loss {it}")
+        assert_close(lp, g["losses_prot"][it], 5e-4, 0, f"loss_prot {it}")
+        assert_close(ll, g["losses_lig"][it], 5e-4, 0, f"loss_lig {it}")
+    sd = model.state_dict()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    ema = dict(zip(names, tr.ema.shadow_params))
+    for key in ("transformer.blocks_prot.0.attn_qkv.weight", "transformer.blocks_lig.1.mlp.2.bias",
+                "transformer.ligand_output.linear.weight", "transformer.protein_embed.embedding.weight"):
+        assert_close(sd[key], g["final." + key], 2e-3, 1e-4, key)
+        assert_close(ema[key], g["ema." + key], 2e-3, 1e-4, "ema " + key)
+    assert tr.ema.num_updates == 3 and tr.opt_steps == 6
+
+
+def test_cross_trainer_task_freezing():
+    """protein_only freezes every 'lig' parameter (run_train_protlig_cross_att.py:211-215): they receive no update."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd.train import CrossAttTrainer
+    torch.manual_seed(3)
+    model = ProteinLigandDiffusionModel(_cfg(64, 2, 32, 1)).to(DEV)
+    load_sd(model, seeded_state_dict(cross_shapes(64, 32, 1), seed=3, std=0.05))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    tr = CrossAttTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(DEV), graph_lib.Absorbing(36), graph_lib.Absorbing(2364),
+                         dict(lr=1e-3, weight_decay=0.0, warmup=0, grad_clip=1.0), task="protein_only", world_size=1)
+    assert all(("lig" in n) == (not p.requires_grad) for n, p in model.named_parameters())
+    loss = tr.train_step({"prot_tokens": torch.randint(0, 33, (2, 16), device=DEV)})
+    assert torch.isfinite(loss)
+    after = model.state_dict()
+    changed = {k for k in before if not torch.equal(before[k], after[k])}
+    assert changed and all("lig" not in k for k in changed)
