@@ -120,15 +120,18 @@ int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float
 
 /* bias_dropout_add_scale (fused_add_dropout_scale.py:13-48), bias == None at every reference call site:
  * out = residual + gate_b * (a * keep / (1-p)).  residual/out fp32 [M,D], a in `a_dtype`, gate rows as in
- * ln_modulate; keep: optional uint8 [M,D] dropout keep-mask (NULL = inference / p = 0), inv_keep = 1/(1-p). */
+ * ln_modulate.  Dropout (p = model.dropout in training): either keep = uint8 [M,D] keep-mask supplied by the caller,
+ * or keep == NULL and p_drop > 0: the mask is generated in the kernel from a counter-based hash of (seed, element
+ * index), so the backward call with the same seed reproduces it and no mask is stored; keep == NULL and p_drop == 0:
+ * inference.  inv_keep = 1/(1-p) in both dropout forms. */
 int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, const void* gate, int mod_dtype,
-                           int64_t mod_stride, const uint8_t* keep, float inv_keep, float* out, int64_t M,
-                           int64_t L, int D, sedd_stream_t stream);
+                           int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed, float p_drop,
+                           float* out, int64_t M, int64_t L, int D, sedd_stream_t stream);
 /* backward: da = dout * gate_b * keep*inv_keep (a_dtype); per-chunk partial sums of dgate = sum_l dout*a*keep*inv
  * to ws fp32 [nchunk, D] (same chunking as sedd_ln_bwd_chunks), folded by sedd_gate_residual_bwd_reduce. */
 int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
-                           int64_t mod_stride, const uint8_t* keep, float inv_keep, void* da, float* ws,
-                           int64_t M, int64_t L, int D, sedd_stream_t stream);
+                           int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed, float p_drop,
+                           void* da, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
 int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L, int D,
                                   sedd_stream_t stream);
 

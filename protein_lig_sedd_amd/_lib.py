@@ -35,8 +35,8 @@ SIGNATURES = {
     "sedd_ln_modulate_fwd": "pppppilpippllip",
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
-    "sedd_gate_residual_fwd": "ppipilpfpllip",
-    "sedd_gate_residual_bwd": "ppipilpfppllip",
+    "sedd_gate_residual_fwd": "ppipilpflfpllip",
+    "sedd_gate_residual_bwd": "ppipilpflfppllip",
     "sedd_gate_residual_bwd_reduce": "ppl" + "llip",
     "sedd_rotary_qkv": "pippiiiiip",
     "sedd_gelu_fwd": "ppilp",

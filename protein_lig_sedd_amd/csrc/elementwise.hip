@@ -275,11 +275,28 @@ extern "C" int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* ds
 }
 
 // ====================================================================================== gated residual fwd
+// Counter-based dropout: the keep decision of element e is a pure function of (seed, e), so forward and backward
+// regenerate the same mask instead of writing / reading a [M, D] byte mask (and no torch RNG kernel runs per block).
+// Two rounds of a 32-bit avalanche hash (lowbias32) per group of 4 consecutive elements give four 16-bit uniforms;
+// keep <=> u16 >= thr16 with thr16 = round(p * 65536).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float4 keep4_hashed(uint64_t seed, int64_t off, uint32_t thr16, float inv_keep) {
+    const uint64_t q = (uint64_t)off >> 2;
+    const uint32_t h0 = mix32(mix32((uint32_t)q ^ (uint32_t)seed) + (uint32_t)(q >> 32) + (uint32_t)(seed >> 32));
+    const uint32_t h1 = mix32(h0 ^ 0x9e3779b9U);
+    return make_float4((h0 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h0 >> 16) >= thr16 ? inv_keep : 0.f,
+                       (h1 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h1 >> 16) >= thr16 ? inv_keep : 0.f);
+}
+
 // fused_add_dropout_scale.py:13-48 with bias == None: out = residual + gate_b * dropout(a)
 template <typename TA, typename TM>
 __global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restrict__ res, const TA* __restrict__ a,
                                                            const TM* __restrict__ gate, int64_t mod_stride,
                                                            const uint8_t* __restrict__ keep, float inv_keep,
+                                                           uint64_t seed, uint32_t thr16,
                                                            float* __restrict__ out, int64_t M, int64_t L, int D) {
     const int64_t nvec = M * (int64_t)(D / 4);
     const int dv = D / 4;
@@ -292,6 +309,9 @@ __global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restri
             const uchar4 k = *reinterpret_cast<const uchar4*>(keep + off);
             av.x *= k.x ? inv_keep : 0.f; av.y *= k.y ? inv_keep : 0.f;
             av.z *= k.z ? inv_keep : 0.f; av.w *= k.w ? inv_keep : 0.f;
+        } else if (thr16) {
+            const float4 kk = keep4_hashed(seed, off, thr16, inv_keep);
+            av.x *= kk.x; av.y *= kk.y; av.z *= kk.z; av.w *= kk.w;
         }
         const float4 g = load4<TM>(gate + (row / L) * mod_stride + c);
         const float4 r = load4<float>(res + off);
@@ -301,8 +321,11 @@ __global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restri
 
 extern "C" int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, const void* gate,
                                       int mod_dtype, int64_t mod_stride, const uint8_t* keep, float inv_keep,
-                                      float* out, int64_t M, int64_t L, int D, sedd_stream_t stream) {
+                                      uint64_t seed, float p_drop, float* out, int64_t M, int64_t L, int D,
+                                      sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_fwd: bad dtype");
+    SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "gate_residual_fwd: p_drop %f", (double)p_drop);
+    const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
     SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "gate_residual_fwd: bad sizes");
     if (D <= 0 || D % 4 != 0 || mod_stride % 4 != 0) {
         sedd_set_error("gate_residual_fwd: D=%d unsupported (need D %% 4 == 0)", D);
@@ -313,7 +336,7 @@ extern "C" int sedd_gate_residual_fwd(const float* residual, const void* a, int 
     const dim3 grid(sedd_grid_for(M * (D / 4), TPB, 256 * 16));
     DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
         hipLaunchKernelGGL((gate_res_fwd_kernel<TA, TM>), grid, dim3(TPB), 0, (hipStream_t)stream, residual,
-                           (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, out, M, L, D)));
+                           (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, out, M, L, D)));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
@@ -324,6 +347,7 @@ template <typename TA, typename TM>
 __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restrict__ dout, const TA* __restrict__ a,
                                                            const TM* __restrict__ gate, int64_t mod_stride,
                                                            const uint8_t* __restrict__ keep, float inv_keep,
+                                                           uint64_t seed, uint32_t thr16,
                                                            TA* __restrict__ da, float* __restrict__ ws, int64_t L,
                                                            int D) {
     __shared__ float red[(TPB / 64) * 256];
@@ -344,6 +368,8 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
                 if (keep) {
                     const uchar4 k = *reinterpret_cast<const uchar4*>(keep + off);
                     kk = make_float4(k.x ? inv_keep : 0.f, k.y ? inv_keep : 0.f, k.z ? inv_keep : 0.f, k.w ? inv_keep : 0.f);
+                } else if (thr16) {
+                    kk = keep4_hashed(seed, off, thr16, inv_keep);
                 }
                 store4<TA>(da + off, make_float4(d.x * g.x * kk.x, d.y * g.y * kk.y, d.z * g.z * kk.z, d.w * g.w * kk.w));
                 acc.x += d.x * av.x * kk.x; acc.y += d.y * av.y * kk.y;
@@ -365,9 +391,12 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
 }
 
 extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
-                                      int64_t mod_stride, const uint8_t* keep, float inv_keep, void* da, float* ws,
-                                      int64_t M, int64_t L, int D, sedd_stream_t stream) {
+                                      int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed,
+                                      float p_drop, void* da, float* ws, int64_t M, int64_t L, int D,
+                                      sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_bwd: bad dtype");
+    SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "gate_residual_bwd: p_drop %f", (double)p_drop);
+    const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
     SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "gate_residual_bwd: bad sizes");
     if (D <= 0 || D % 4 != 0 || mod_stride % 4 != 0) {
         sedd_set_error("gate_residual_bwd: D=%d unsupported (need D %% 4 == 0)", D);
@@ -378,7 +407,7 @@ extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dt
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
     DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
         hipLaunchKernelGGL((gate_res_bwd_kernel<TA, TM>), dim3((unsigned)nchunk), dim3(TPB), 0, (hipStream_t)stream,
-                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, (TA*)da, ws, L, D)));
+                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, (TA*)da, ws, L, D)));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

@@ -133,9 +133,9 @@ def compact_rotary(cos, sin):
 
 
 def dropout_mask(shape, p, device):
-    keep = torch.empty(shape, dtype=torch.uint8, device=device)
-    keep.bernoulli_(1.0 - p)
-    return keep
+    """dropout state of one bias_dropout_add_scale site: a (seed, p) pair — the kernels derive the keep decision of
+    every element from a counter-based hash, forward and backward alike (no [M, D] mask tensor, no torch RNG kernel)."""
+    return ops.DropSeed(p)
 
 
 # ------------------------------------------------------------------------------------------------- DDiT block

@@ -274,12 +274,33 @@ def ln_modulate_bwd(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dsc
           "sedd_ln_modulate_bwd_reduce")
 
 
+class DropSeed:
+    """Dropout by counter-based hash: (seed, p) stand in for a [M, D] keep-mask; forward and backward regenerate the
+    same mask in the kernel (sedd_gate_residual_fwd / _bwd)."""
+    __slots__ = ("seed", "p")
+    _counter = 0
+
+    def __init__(self, p, seed=None):
+        if seed is None:
+            DropSeed._counter += 1
+            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + DropSeed._counter * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+        self.seed, self.p = int(seed), float(p)
+
+
+def _keep_args(keep):
+    """-> (mask pointer, seed, p_drop) for a uint8 mask tensor, a DropSeed or None."""
+    if isinstance(keep, DropSeed):
+        return None, keep.seed, keep.p
+    return _p(keep), 0, 0.0
+
+
 def gate_residual_fwd(residual, a, gate, keep=None, inv_keep=1.0):
     B, L, D = residual.shape
     out = torch.empty_like(residual)
     g, mdt, ms = _mod_args(gate)
-    check(lib().sedd_gate_residual_fwd(_p(residual), _p(a), _dt(a), _p(g), mdt, ms, _p(keep), float(inv_keep), _p(out),
-                                       B * L, L, D, _stream()), "sedd_gate_residual_fwd")
+    kp, seed, pd = _keep_args(keep)
+    check(lib().sedd_gate_residual_fwd(_p(residual), _p(a), _dt(a), _p(g), mdt, ms, kp, float(inv_keep), seed, pd,
+                                       _p(out), B * L, L, D, _stream()), "sedd_gate_residual_fwd")
     return out
 
 
@@ -291,7 +312,8 @@ def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0):
     nchunk = lib().sedd_ln_bwd_chunks(M, L)
     ws = torch.empty(nchunk * D, dtype=torch.float32, device=dout.device)
     g, mdt, ms = _mod_args(gate)
-    check(lib().sedd_gate_residual_bwd(_p(dout), _p(a), _dt(a), _p(g), mdt, ms, _p(keep), float(inv_keep), _p(da),
+    kp, seed, pd = _keep_args(keep)
+    check(lib().sedd_gate_residual_bwd(_p(dout), _p(a), _dt(a), _p(g), mdt, ms, kp, float(inv_keep), seed, pd, _p(da),
                                        _p(ws), M, L, D, _stream()), "sedd_gate_residual_bwd")
     check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), M, L, D, _stream()),
           "sedd_gate_residual_bwd_reduce")

@@ -22,7 +22,7 @@ def _prototypes():
         for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             if "*" in a or a.startswith("sedd_stream_t"):
                 sig += "p"
-            elif a.startswith("int64_t"):
+            elif a.startswith("int64_t") or a.startswith("uint64_t"):
                 sig += "l"
             elif a.startswith("float"):
                 sig += "f"

@@ -252,6 +252,33 @@ def test_gelu_silu_embed_epilogue_colsum_transpose():
     assert torch.equal(ops.cast(a.float(), torch.bfloat16), a.float().bfloat16())
 
 
+def test_hashed_dropout_is_consistent_between_forward_and_backward():
+    """counter-based dropout (seed instead of a stored mask): keep rate = 1 - p, the backward regenerates the forward's
+    mask exactly, different seeds give different masks, and the result equals the explicit-mask path."""
+    ops = _ops()
+    B, L, D, p = 3, 70, 768, 0.1
+    inv = 1.0 / (1.0 - p)
+    ones = torch.ones(B, L, D, device=DEV)
+    gate = torch.ones(B, D, device=DEV)
+    ds = ops.DropSeed(p, seed=12345)
+    mask = ops.gate_residual_fwd(torch.zeros_like(ones), ones, gate, ds, inv) > 0
+    frac = float(mask.float().mean())
+    assert abs(frac - (1 - p)) < 0.005, frac
+    assert abs(float(mask.float().mean(dim=(0, 1)).min()) - (1 - p)) < 0.15  # no dead columns
+    mask2 = ops.gate_residual_fwd(torch.zeros_like(ones), ones, gate, ops.DropSeed(p, seed=12346), inv) > 0
+    assert 0.1 < float((mask ^ mask2).float().mean()) < 0.3
+    torch.manual_seed(0)
+    res, a = torch.randn(B, L, D, device=DEV), torch.randn(B, L, D, device=DEV).bfloat16()
+    g = torch.randn(B, 6 * D, device=DEV).bfloat16()[:, 2 * D:3 * D]
+    dout = torch.randn(B, L, D, device=DEV)
+    keep = mask.to(torch.uint8)
+    assert torch.equal(ops.gate_residual_fwd(res, a, g, ds, inv), ops.gate_residual_fwd(res, a, g, keep, inv))
+    dg1, dg2 = torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    da1 = ops.gate_residual_bwd(dout, a, g, dg1, ds, inv)
+    da2 = ops.gate_residual_bwd(dout, a, g, dg2, keep, inv)
+    assert torch.equal(da1, da2) and torch.equal(dg1, dg2)
+
+
 def _ref_attn(q, k, v, mask):
     return O.softmax_attention(q, k, v, mask)
 
