@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsedd_hip.so")
+LIB_PATH = os.environ.get("SEDD_HIP_LIB") or os.path.join(_HERE, "libsedd_hip.so")  # (override: A/B builds)
 
 # enums (include/sedd_hip.h)
 F32, BF16 = 0, 1
