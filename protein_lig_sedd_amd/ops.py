@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/sedd_hip.h). Each takes/returns torch CUDA tensors, launches on
 torch's current stream and allocates outputs with torch's caching allocator. No arithmetic happens in Python."""
+import os
+
 import torch
 
 from . import _lib as _L
@@ -406,6 +408,8 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
 
 
 def gemm_nt_dgelu_supported(A, B, pre):
+    if os.environ.get("SEDD_NO_DGELU"):
+        return False
     M, K = A.shape
     N = B.shape[0]
     return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and pre.dtype == torch.bfloat16 and M >= 192
