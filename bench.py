@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=8, help="Analytic sampler steps timed for the seqs/s side metric")
     args = ap.parse_args()
+    if os.environ.get("SEDD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SEDD_BENCH_WATCHDOG"]), exit=True)
 
     from protein_lig_sedd_amd import graph_lib, noise_lib, ops, sampling
     from protein_lig_sedd_amd.model.transformer import _SEDD
@@ -157,8 +160,10 @@ def main():
     torch.manual_seed(1234 + rank)  # per-rank data / noise
     batches = [torch.randint(0, cfg.tokens, (B, L), device=dev) for _ in range(4)]
 
+    multi = dist.is_initialized()  # world > 1, or the 1-rank rehearsal of the collective path (SEDD_DP_FORCE=1)
+
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +178,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.PROF.summary()
     ops.PROF = None
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -232,7 +237,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

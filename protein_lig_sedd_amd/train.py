@@ -72,11 +72,14 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SEDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
+        if backend != "nccl":  # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo moves the bytes)
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SEDD_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_PORT", "29500")
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
@@ -109,10 +112,13 @@ class SEDDTrainer:
         dev = self.flat.p.device
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self._norm = torch.ones(2, dtype=torch.float32, device=dev)
-        self.overlap = overlap and self.world > 1
+        # SEDD_DP_FORCE=1 runs every collective of the N > 1 path over a 1-rank group (rehearsal of the RCCL stream
+        # ordering on a single GPU); SEDD_DP_OVERLAP=0 falls back to one blocking all-reduce after backward
+        self.dp = self.world > 1 or (os.environ.get("SEDD_DP_FORCE") == "1" and dist.is_initialized())
+        self.overlap = overlap and self.dp and os.environ.get("SEDD_DP_OVERLAP", "1") != "0"
         self._pending = []
         self._buckets = self._make_buckets()
-        if self.world > 1:
+        if self.dp:
             self.broadcast_parameters()
 
     # ---- gradient buckets: [embedding + sigma_map], one per block, [output layer] -------------------------------
@@ -181,7 +187,7 @@ class SEDDTrainer:
         """Finish the gradient all-reduce (SUM; the 1/world averaging is folded into the optimiser kernel's grad_scale):
         block buckets were launched asynchronously from the backward hooks, the leftovers (embedding, sigma_map, output
         layer) go now; then wait for everything."""
-        if self.world <= 1:
+        if not getattr(self, "dp", self.world > 1):
             return
         fl = self.flat
         if self.overlap:
@@ -392,7 +398,7 @@ class CrossAttTrainer(SEDDTrainer):
         out = self.calc_loss(batch, task, t=t, perturbed=perturbed)
         loss = out[0].mean() if task == "joint" else out.mean()
         loss.backward()
-        if self.world > 1:
+        if self.dp:
             dist.all_reduce(fl.g, group=self.pg)
         self.step_count += 1
         gscale = 1.0 / self.world
