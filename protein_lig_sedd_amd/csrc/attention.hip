@@ -23,6 +23,20 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Occupancy targets (waves per SIMD) for the bf16 d <= 64 instantiations, where the register budget allows them
+// without spilling (same-device A/B: forward 119 -> 96 us, backward 432 -> 351 us at B64 H12 L512 d64 together with
+// -amdgpu-mfma-vgpr-form, which keeps the MFMA accumulators the softmax works on out of the AGPR half).
+#define ATTN_WPE(n) __attribute__((amdgpu_waves_per_eu(n)))
+#ifndef ATTN_FWD_WPE
+#define ATTN_FWD_WPE 3
+#endif
+#ifndef ATTN_DQ_WPE
+#define ATTN_DQ_WPE 1
+#endif
+#ifndef ATTN_DKV_WPE
+#define ATTN_DKV_WPE 2
+#endif
+template <typename T, int D> constexpr int wpe_if_small(int n) { return sizeof(T) == 2 && D <= 64 ? n : 1; }
 #define TILE 64          // rows of a staged LDS tile (keys in fwd / dQ, queries in dK/dV)
 #define OWN_PER_WAVE 32  // rows owned by a wave (2 MFMA tiles)
 #define OWN_PER_BLOCK 128
@@ -30,7 +44,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LN2 0.6931471805599453f
 
 template <typename T> struct Op;
-template <> struct Op<bf16_t> { using type = bf16x8; static constexpr int KS = 32; static constexpr int PAD = 8; };
+#ifndef ATTN_PAD
+#define ATTN_PAD 16  // row pitch = 2(D + 16) B = 32 mod 64: ds_read_b128 row fragments and ds_read_b64_tr_b16 are conflict-free
+#endif
+template <> struct Op<bf16_t> { using type = bf16x8; static constexpr int KS = 32; static constexpr int PAD = ATTN_PAD; };
 template <> struct Op<float> { using type = float; static constexpr int KS = 4; static constexpr int PAD = 4; };
 
 template <typename T, int D> struct RowFrag { typename Op<T>::type v[D / Op<T>::KS]; };
@@ -108,6 +125,43 @@ __device__ __forceinline__ void mma_tr(f32x4 (&accT)[D / 16], const T* X, const 
     }
 }
 
+// Same for the wave's two own 16-row tiles at once: the transposed X fragment is read once and feeds both.
+template <typename T, int D>
+__device__ __forceinline__ void mma_tr2(f32x4 (&acc0)[D / 16], f32x4 (&acc1)[D / 16], const T* X, const f32x4 (&W0)[4],
+                                        const f32x4 (&W1)[4], int lane) {
+#ifdef ATTN_NO_SHARE
+    mma_tr<T, D>(acc0, X, W0, lane);
+    mma_tr<T, D>(acc1, X, W1, lane);
+#else
+    if constexpr (sizeof(T) == 2) {
+        constexpr int LS = D + Op<T>::PAD;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 b0, b1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b0[j] = (__bf16)W0[2 * s][j]; b0[4 + j] = (__bf16)W0[2 * s + 1][j];
+                b1[j] = (__bf16)W1[2 * s][j]; b1[4 + j] = (__bf16)W1[2 * s + 1][j];
+            }
+            const T* r0 = X + (32 * s + 4 * g + q) * LS + 4 * p;
+            const T* r1 = r0 + 16 * LS;
+#pragma unroll
+            for (int dt = 0; dt < D / 16; ++dt) {
+                union { struct { s16x4 lo, hi; } s; bf16x8 v; } a;
+                a.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + dt * 16));
+                a.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r1 + dt * 16));
+                acc0[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0, acc0[dt], 0, 0, 0);
+                acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1, acc1[dt], 0, 0, 0);
+            }
+        }
+    } else {
+        mma_tr<T, D>(acc0, X, W0, lane);
+        mma_tr<T, D>(acc1, X, W1, lane);
+    }
+#endif
+}
+
 // Staging of rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks, split
 // in two halves: stage_load puts the tile into registers, stage_store parks it in LDS.  The kernels issue the loads
 // of tile t+1 right after tile t has been parked, so the global-memory latency runs under tile t's MFMA / softmax work.
@@ -158,7 +212,7 @@ struct AttnShape {
 
 // ==================================================================================================== forward
 template <typename T, int D>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_FWD_WPE))) attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v, T* __restrict__ o,
                                                        float* __restrict__ lse, const uint8_t* __restrict__ mask,
                                                        AttnShape sh) {
@@ -253,8 +307,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ q, 
             lsum[mt] = lsum[mt] * alpha + rs;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] *= alpha;
-            mma_tr<T, D>(acc[mt], Vs, S[mt], lane);
         }
+        mma_tr2<T, D>(acc[0], acc[1], Vs, S[0], S[1], lane);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -304,7 +358,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ o
 
 // ================================================================================================ dQ kernel
 template <typename T, int D>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE))) attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, const T* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           const float* __restrict__ delta,
@@ -376,8 +430,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
                     S[mt][t][r] = p * (dP[mt][t][r] - dl[mt]) * sh.scale;  // dS^T
                 }
             }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) mma_tr<T, D>(acc[mt], Ks, S[mt], lane);
+        mma_tr2<T, D>(acc[0], acc[1], Ks, S[0], S[1], lane);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -390,7 +443,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const T* __restrict__ 
 
 // ============================================================================================ dK / dV kernel
 template <typename T, int D>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE))) attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                            const T* __restrict__ v, const T* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
@@ -472,11 +525,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const T* __restrict__
                     dP[mt][t][r] = p * (dP[mt][t][r] - dl) * sh.scale;        // dS
                 }
             }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            mma_tr<T, D>(adv[mt], dOs, S[mt], lane);
-            mma_tr<T, D>(adk[mt], Qs, dP[mt], lane);
-        }
+        mma_tr2<T, D>(adv[0], adv[1], dOs, S[0], S[1], lane);
+        mma_tr2<T, D>(adk[0], adk[1], Qs, dP[0], dP[1], lane);
     }
 #undef DKV_LOAD
 #pragma unroll

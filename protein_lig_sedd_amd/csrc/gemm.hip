@@ -313,8 +313,15 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 //   k-contiguous MFMA fragments come out of LDS through the transposing read ds_read_b64_tr_b16, which hands lane
 //   (g, i) the four rows 4g..4g+3 of column i: a fragment is two of them (rows 4g+j and 16+4g+j) — a permutation of the
 //   32 k values that both operands share, which a sum over k allows.
-template <typename TO, int BN_, int NST, bool TN, bool DG>
-__global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
+// NW = 8: one 512-thread block per CU.  NW = 4 (BN_ = 128 only, experimental: SEDD_GEMM_NW4=1|2): 256-thread blocks
+// with the same 128 x 64 wave tile as the 256-wide NW = 8 kernel and a 3-deep ring (72 KB), so TWO blocks share a CU
+// and one block's LDS-DMA issue, barriers and epilogue run under the other block's MFMAs; the output staging region
+// then aliases ring stage NST-1, which the next tile's prologue (stages 0..NST-2) leaves alone until after that tile's
+// first two barriers.  Measured equal to the 8-wave kernels within noise (the 3-deep ring has one K step of
+// look-ahead), so it is not the default.
+template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
+gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
                                                             TO* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int epi,
@@ -322,14 +329,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
                                                             int64_t N, int64_t Kper, int64_t Ktot, int ntn,
                                                             int ntiles, int splitk, float4* __restrict__ slabs,
                                                             float* __restrict__ colsum) {
-    constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
-    constexpr int LA = 2, LB = BN_ / 128, LPT = LA + LB;              // DMA wave-instructions per stage
+    constexpr int WN = BN_ / 64, WM = NW / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
+    constexpr int LA = BIG_BM / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
+    constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;                 // K-loop unroll: whole ring turns, even
+    static_assert(NW == 8 || (NW == 4 && BN_ == 128), "4-wave blocks carry 256 x 128 tiles");
     constexpr int ASLOTS = BIG_BM * 4, SLOTS = (BIG_BM + BN_) * 4;    // 16-byte slots per stage
     constexpr int TMH = TM / 2;
     constexpr bool STAGED = sizeof(TO) == 2;                          // bf16 outputs leave through the staging region
-    static_assert(NST >= 4 && NST <= 6 && NST % 2 == 0, "ring depth (even: the fragment register sets alternate)");
+    static_assert(NST >= 3 && NST <= 6, "ring depth");
+    static_assert(NW == 8 || SLOTS * 16 >= NW * StageCfg<TO>::REGION, "staging fits a ring stage");
     __shared__ __attribute__((aligned(16))) uint4 smem[NST][SLOTS];
-    __shared__ __attribute__((aligned(16))) unsigned char stage_lds[STAGED ? 8 * StageCfg<TO>::REGION : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_own[STAGED && NW == 8 ? 8 * StageCfg<TO>::REGION : 16];
+    unsigned char* const stage_lds = NW == 8 ? stage_own : reinterpret_cast<unsigned char*>(&smem[NST - 1][0]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -366,12 +377,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
         n0 = (int64_t)(wg_ % ntn) * BN_;                                                                             \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
             if constexpr (TN) { /* wave-instruction j = 2 token rows x 512 B */                                      \
-                const int r = (i * 8 + wave) * 2 + (lane >> 5);                                                      \
+                const int r = (i * NW + wave) * 2 + (lane >> 5);                                                      \
                 int64_t col = m0 + (((lane & 31) ^ (2 * (r & 7))) << 3);                                             \
                 col = col < M ? col : 0;                                                                             \
                 srcA[i] = A + (kbeg + r) * lda + col;                                                                \
             } else {                                                                                                 \
-                const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                     \
+                const int r = (i * NW + wave) * 16 + (lane >> 2);                                                     \
                 const int c = (lane & 3) ^ ((r >> 1) & 3);                                                           \
                 int64_t ar = m0 + r;                                                                                 \
                 ar = ar < M ? ar : M - 1;                                                                            \
@@ -381,12 +392,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
         _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                             \
             if constexpr (TN) {                                                                                      \
                 constexpr int CPR = BN_ / 8; /* 16-byte chunks per B row */                                          \
-                const int r = (i * 8 + wave) * (64 / CPR) + lane / CPR;                                              \
+                const int r = (i * NW + wave) * (64 / CPR) + lane / CPR;                                              \
                 int64_t col = n0 + (((lane % CPR) ^ (2 * (r & 7))) << 3);                                            \
                 col = col < N ? col : 0;                                                                             \
                 srcB[i] = B + (kbeg + r) * ldb + col;                                                                \
             } else {                                                                                                 \
-                const int r = (i * 8 + wave) * 16 + (lane >> 2);                                                     \
+                const int r = (i * NW + wave) * 16 + (lane >> 2);                                                     \
                 const int c = (lane & 3) ^ ((r >> 1) & 3);                                                           \
                 int64_t br = n0 + r;                                                                                 \
                 br = br < N ? br : N - 1;                                                                            \
@@ -397,9 +408,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
 #define BIG_STAGE(st, kt)                                                                                            \
     do {                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                               \
-            lds_dma16(srcA[i] + (int64_t)(kt) * ksA, ring + ((st) * SLOTS + (i * 8 + wave) * 64) * 16);              \
+            lds_dma16(srcA[i] + (int64_t)(kt) * ksA, ring + ((st) * SLOTS + (i * NW + wave) * 64) * 16);              \
         _Pragma("unroll") for (int i = 0; i < LB; ++i)                                                               \
-            lds_dma16(srcB[i] + (int64_t)(kt) * ksB, ring + ((st) * SLOTS + ASLOTS + (i * 8 + wave) * 64) * 16);     \
+            lds_dma16(srcB[i] + (int64_t)(kt) * ksB, ring + ((st) * SLOTS + ASLOTS + (i * NW + wave) * 64) * 16);     \
     } while (0)
 #define BIG_PROLOGUE()                                                                                               \
     do {                                                                                                             \
@@ -466,12 +477,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const bf16_t* __rest
         __builtin_amdgcn_s_barrier();
         BIG_READ_A(a_lo, 0, 0);
         BIG_READ_B(0, 0);
-        for (int kt0 = 0; kt0 < nkt; kt0 += NST) {
+        for (int kt0 = 0; kt0 < nkt; kt0 += UNR) {
 #pragma unroll
-            for (int s = 0; s < NST; ++s) {
+            for (int s = 0; s < UNR; ++s) {
                 const int kt = kt0 + s;
                 if (kt < nkt) {
-                    BIG_READ_A(a_hi, s, TMH);
+                    BIG_READ_A(a_hi, s % NST, TMH);
                     BIG_MMA(a_lo, 0, s & 1);
                     if (kt + 1 < nkt) {
                         const int rem = nkt - 2 - kt;
@@ -897,7 +908,16 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
                                        (float4*)nullptr, colsum);
             } else if (out_dtype == SEDD_BF16) {
-                if (wide) BIG_LAUNCH(bf16_t, 256, 4);
+                static const int nw4 = getenv("SEDD_GEMM_NW4") ? atoi(getenv("SEDD_GEMM_NW4")) : 0;
+                if (nw4 && splitk == 1 && (nw4 == 2 || !wide)) {
+                    // two 256-thread blocks per CU, 256 x 128 tiles
+                    const int64_t tn4 = (N + 127) / 128, tiles4 = tm * tn4;
+                    const dim3 g4((unsigned)(tiles4 < 512 ? tiles4 : 512));
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 3, false, false, 4>), g4, dim3(256), 0, st,
+                                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
+                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn4, (int)tiles4, 1,
+                                       (float4*)nullptr, colsum);
+                } else if (wide) BIG_LAUNCH(bf16_t, 256, 4);
                 else BIG_LAUNCH(bf16_t, 128, 4);
             } else {
                 if (wide) BIG_LAUNCH(float, 256, 4);
