@@ -125,41 +125,59 @@ __device__ __forceinline__ void mma_tr(f32x4 (&accT)[D / 16], const T* X, const 
     }
 }
 
-// Same for the wave's two own 16-row tiles at once: the transposed X fragment is read once and feeds both.
+// The same product for the wave's two own 16-row tiles at once and for HALF of the staged tile (rows 32h .. 32h+31,
+// i.e. the score fragments t = 2h and 2h+1): the transposed X fragment is read once and feeds both own tiles, and the
+// half-tile granularity lets the kernels start these MFMAs as soon as the first two score fragments are through the
+// softmax arithmetic while the other two are still in the MFMA pipe / VALU.
 template <typename T, int D>
-__device__ __forceinline__ void mma_tr2(f32x4 (&acc0)[D / 16], f32x4 (&acc1)[D / 16], const T* X, const f32x4 (&W0)[4],
-                                        const f32x4 (&W1)[4], int lane) {
-#ifdef ATTN_NO_SHARE
-    mma_tr<T, D>(acc0, X, W0, lane);
-    mma_tr<T, D>(acc1, X, W1, lane);
-#else
+__device__ __forceinline__ void mma_tr_pair(f32x4 (&acc0)[D / 16], f32x4 (&acc1)[D / 16], const T* X, int h,
+                                            const f32x4& W0a, const f32x4& W0b, const f32x4& W1a, const f32x4& W1b,
+                                            int lane) {
+    constexpr int LS = D + Op<T>::PAD;
+    const int g = lane >> 4, i = lane & 15;
     if constexpr (sizeof(T) == 2) {
-        constexpr int LS = D + Op<T>::PAD;
-        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int q = i >> 2, p = i & 3;
+        bf16x8 b0, b1;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 b0, b1;
+        for (int j = 0; j < 4; ++j) {
+            b0[j] = (__bf16)W0a[j]; b0[4 + j] = (__bf16)W0b[j];
+            b1[j] = (__bf16)W1a[j]; b1[4 + j] = (__bf16)W1b[j];
+        }
+        const T* r0 = X + (32 * h + 4 * g + q) * LS + 4 * p;
+        const T* r1 = r0 + 16 * LS;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                b0[j] = (__bf16)W0[2 * s][j]; b0[4 + j] = (__bf16)W0[2 * s + 1][j];
-                b1[j] = (__bf16)W1[2 * s][j]; b1[4 + j] = (__bf16)W1[2 * s + 1][j];
-            }
-            const T* r0 = X + (32 * s + 4 * g + q) * LS + 4 * p;
-            const T* r1 = r0 + 16 * LS;
-#pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) {
-                union { struct { s16x4 lo, hi; } s; bf16x8 v; } a;
-                a.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + dt * 16));
-                a.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r1 + dt * 16));
-                acc0[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0, acc0[dt], 0, 0, 0);
-                acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1, acc1[dt], 0, 0, 0);
-            }
+        for (int dt = 0; dt < D / 16; ++dt) {
+            union { struct { s16x4 lo, hi; } s; bf16x8 v; } a;
+            a.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + dt * 16));
+            a.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r1 + dt * 16));
+            acc0[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0, acc0[dt], 0, 0, 0);
+            acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1, acc1[dt], 0, 0, 0);
         }
     } else {
-        mma_tr<T, D>(acc0, X, W0, lane);
-        mma_tr<T, D>(acc1, X, W1, lane);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T* row = X + (16 * (2 * h + tt) + 4 * g + r) * LS + i;
+                const float w0 = tt ? W0b[r] : W0a[r], w1 = tt ? W1b[r] : W1a[r];
+#pragma unroll
+                for (int dt = 0; dt < D / 16; ++dt) {
+                    const float x = row[dt * 16];
+                    acc0[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, w0, acc0[dt], 0, 0, 0);
+                    acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, w1, acc1[dt], 0, 0, 0);
+                }
+            }
     }
-#endif
+}
+
+// max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without an LDS round trip: v_permlane16_swap /
+// v_permlane32_swap exchange rows between two copies of the value
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ float max_over_rows(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // Staging of rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks, split
@@ -211,11 +229,12 @@ struct AttnShape {
 };
 
 // ==================================================================================================== forward
-template <typename T, int D>
-__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_FWD_WPE))) attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                       const T* __restrict__ v, T* __restrict__ o,
-                                                       float* __restrict__ lse, const uint8_t* __restrict__ mask,
-                                                       AttnShape sh) {
+// PLAIN: no key mask and Lk a multiple of TILE — every score is valid (the training shapes); the general
+// instantiation carries the per-key validity selects.
+template <typename T, int D, bool PLAIN>
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_FWD_WPE)))
+attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ o,
+                float* __restrict__ lse, const uint8_t* __restrict__ mask, AttnShape sh) {
     constexpr int LS = D + Op<T>::PAD;
     __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
     __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_FWD_WPE
     const T* qb = q + b * sh.q_bs + (int64_t)h * D;
     const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
     const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
-    const uint8_t* mb = mask ? mask + (int64_t)b * sh.Lk : nullptr;
+    const uint8_t* mb = !PLAIN && mask ? mask + (int64_t)b * sh.Lk : nullptr;
     const float sl2 = sh.scale * LOG2E;
 
     RowFrag<T, D> qf[2];
@@ -260,55 +279,50 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_FWD_WPE
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) S[mt][t] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
         }
-        const bool plain = !mb && k0 + TILE <= sh.Lk;  // no key mask, no ragged tail: the cheap softmax path
-        bool valid[4][4];
-        if (!plain) {
+        if constexpr (!PLAIN) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + 16 * t + 4 * g + r;
-                    valid[t][r] = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+                    const bool valid = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) S[mt][t][r] = valid ? S[mt][t][r] : -INFINITY;
                 }
         }
+        // running max on the raw scores (the scale is positive); the scale is folded into the exponent's fma
+        float ms[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             float mx = -INFINITY;
-            if (plain) {  // max on the raw scores (the scale is positive), scale folded into the exponent's fma
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[mt][t][r]);
-                mx *= sl2;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        S[mt][t][r] = valid[t][r] ? S[mt][t][r] : -INFINITY;
-                        mx = fmaxf(mx, S[mt][t][r] * sl2);
-                    }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m[mt], mx);
-            const float ms = mn == -INFINITY ? 0.f : mn;  // fully masked so far: keep everything at 0
-            const float alpha = fast_exp2(m[mt] - ms);
-            m[mt] = mn;
-            float rs = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(S[mt][t][r], sl2, -ms));
-                    S[mt][t][r] = p;
-                    rs += p;
-                }
-            lsum[mt] = lsum[mt] * alpha + rs;
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[mt][t][r]);
+            mx = max_over_rows(mx) * sl2;
+            const float mn = fmaxf(m[mt], mx);
+            ms[mt] = mn == -INFINITY ? 0.f : mn;  // fully masked so far: keep everything at 0
+            const float alpha = fast_exp2(m[mt] - ms[mt]);
+            m[mt] = mn;
+            lsum[mt] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] *= alpha;
         }
-        mma_tr2<T, D>(acc[0], acc[1], Vs, S[0], S[1], lane);
+        // probabilities and P V, half a tile at a time: the second half's exponentials run under the first half's MFMAs
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(fmaf(S[mt][2 * hh + tt][r], sl2, -ms[mt]));
+                        S[mt][2 * hh + tt][r] = p;
+                        lsum[mt] += p;
+                    }
+            mma_tr_pair<T, D>(acc[0], acc[1], Vs, hh, S[0][2 * hh], S[0][2 * hh + 1], S[1][2 * hh], S[1][2 * hh + 1], lane);
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -357,13 +371,12 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ o
 }
 
 // ================================================================================================ dQ kernel
-template <typename T, int D>
-__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE))) attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                          const T* __restrict__ v, const T* __restrict__ dout,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ delta,
-                                                          const uint8_t* __restrict__ mask, T* __restrict__ dq,
-                                                          AttnShape sh) {
+// The softmax scale of dS = P (dP - delta) * scale is applied once to the finished dQ / dK accumulators.
+template <typename T, int D, bool PLAIN>
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE)))
+attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                   const T* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+                   const uint8_t* __restrict__ mask, T* __restrict__ dq, AttnShape sh) {
     constexpr int LS = D + Op<T>::PAD;
     __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
     __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
@@ -373,7 +386,7 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE)
     const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
     const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
     const T* dob = dout + b * sh.o_bs + (int64_t)h * D;
-    const uint8_t* mb = mask ? mask + (int64_t)b * sh.Lk : nullptr;
+    const uint8_t* mb = !PLAIN && mask ? mask + (int64_t)b * sh.Lk : nullptr;
     const float sl2 = sh.scale * LOG2E;
 
     RowFrag<T, D> qf[2], dof[2];
@@ -407,52 +420,58 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE)
             stage_load<T, D>(rk, kb, sh.kv_ls, k0 + TILE, sh.Lk);
             stage_load<T, D>(rv, vb, sh.kv_ls, k0 + TILE, sh.Lk);
         }
-        f32x4 S[2][4], dP[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const RowFrag<T, D> kf = load_rowfrag<T, D>(Ks + (16 * t + i) * LS, g);
-            const RowFrag<T, D> vf = load_rowfrag<T, D>(Vs + (16 * t + i) * LS, g);
+        for (int hh = 0; hh < 2; ++hh) {  // half a tile at a time (see mma_tr_pair)
+            f32x4 S[2][2], dP[2][2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                S[mt][t] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-                dP[mt][t] = mma_rows<T, D>(vf, dof[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * t + 4 * g + r;
-                const bool valid = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * hh + tt;
+                const RowFrag<T, D> kf = load_rowfrag<T, D>(Ks + (16 * t + i) * LS, g);
+                const RowFrag<T, D> vf = load_rowfrag<T, D>(Vs + (16 * t + i) * LS, g);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const float p = valid ? fast_exp2(S[mt][t][r] * sl2 - lq[mt]) : 0.f;
-                    S[mt][t][r] = p * (dP[mt][t][r] - dl[mt]) * sh.scale;  // dS^T
+                    S[mt][tt] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dP[mt][tt] = mma_rows<T, D>(vf, dof[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
                 }
             }
-        mma_tr2<T, D>(acc[0], acc[1], Ks, S[0], S[1], lane);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool valid = true;
+                    if constexpr (!PLAIN) {
+                        const int key = k0 + 16 * (2 * hh + tt) + 4 * g + r;
+                        valid = key < sh.Lk && (!mb || mb[key < sh.Lk ? key : 0]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const float p = valid ? fast_exp2(fmaf(S[mt][tt][r], sl2, -lq[mt])) : 0.f;
+                        S[mt][tt][r] = p * (dP[mt][tt][r] - dl[mt]);  // dS^T / scale
+                    }
+                }
+            mma_tr_pair<T, D>(acc[0], acc[1], Ks, hh, S[0][0], S[0][1], S[1][0], S[1][1], lane);
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
         if (qrow[mt] < sh.Lq) {
             T* row = dq + b * sh.q_bs + (int64_t)qrow[mt] * sh.q_ls + (int64_t)h * D;
 #pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(row + dt * 16 + 4 * g, acc[mt][dt]);
+            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(row + dt * 16 + 4 * g, acc[mt][dt] * sh.scale);
         }
 }
 
 // ============================================================================================ dK / dV kernel
-template <typename T, int D>
-__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE))) attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                           const T* __restrict__ v, const T* __restrict__ dout,
-                                                           const float* __restrict__ lse,
-                                                           const float* __restrict__ delta,
-                                                           const uint8_t* __restrict__ mask, T* __restrict__ dk,
-                                                           T* __restrict__ dv, AttnShape sh) {
+// PLAIN: no key mask and Lk a multiple of the block's 128 own keys.
+template <typename T, int D, bool PLAIN>
+__global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE)))
+attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                    const T* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+                    const uint8_t* __restrict__ mask, T* __restrict__ dk, T* __restrict__ dv, AttnShape sh) {
     constexpr int LS = D + Op<T>::PAD;
     __shared__ __attribute__((aligned(16))) T Qs[TILE * LS];
     __shared__ __attribute__((aligned(16))) T dOs[TILE * LS];
-    __shared__ float lse_s[TILE], del_s[TILE];
+    __shared__ __attribute__((aligned(16))) float lse_s[TILE], del_s[TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
     const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
     const T* qb = q + b * sh.q_bs + (int64_t)h * D;
@@ -470,7 +489,7 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE
         const bool ok = krow[mt] < sh.Lk;
         kf[mt] = ok ? load_rowfrag<T, D>(kb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
         vf[mt] = ok ? load_rowfrag<T, D>(vb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
-        kvalid[mt] = ok && (!mask || mask[(int64_t)b * sh.Lk + krow[mt]]);
+        kvalid[mt] = PLAIN || (ok && (!mask || mask[(int64_t)b * sh.Lk + krow[mt]]));
     }
     f32x4 adk[2][D / 16], adv[2][D / 16];
 #pragma unroll
@@ -502,31 +521,37 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE
         }
         __syncthreads();
         if (q0 + TILE < sh.Lq) DKV_LOAD(q0 + TILE);
-        f32x4 S[2][4], dP[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const RowFrag<T, D> qf = load_rowfrag<T, D>(Qs + (16 * t + i) * LS, g);
-            const RowFrag<T, D> dof = load_rowfrag<T, D>(dOs + (16 * t + i) * LS, g);
+        for (int hh = 0; hh < 2; ++hh) {  // half a tile at a time (see mma_tr_pair)
+            f32x4 S[2][2], dP[2][2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {  // C/D: col = own key (lane & 15), row = query 16t + 4g + reg
-                S[mt][t] = mma_rows<T, D>(qf, kf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-                dP[mt][t] = mma_rows<T, D>(dof, vf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-            }
-        }
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * hh + tt;
+                const RowFrag<T, D> qf = load_rowfrag<T, D>(Qs + (16 * t + i) * LS, g);
+                const RowFrag<T, D> dof = load_rowfrag<T, D>(dOs + (16 * t + i) * LS, g);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float lq = lse_s[16 * t + 4 * g + r], dl = del_s[16 * t + 4 * g + r];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float p = kvalid[mt] ? fast_exp2(S[mt][t][r] * sl2 - lq) : 0.f;
-                    S[mt][t][r] = p;                                         // P
-                    dP[mt][t][r] = p * (dP[mt][t][r] - dl) * sh.scale;        // dS
+                for (int mt = 0; mt < 2; ++mt) {  // C/D: col = own key (lane & 15), row = query 16t + 4g + reg
+                    S[mt][tt] = mma_rows<T, D>(qf, kf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dP[mt][tt] = mma_rows<T, D>(dof, vf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
                 }
             }
-        mma_tr2<T, D>(adv[0], adv[1], dOs, S[0], S[1], lane);
-        mma_tr2<T, D>(adk[0], adk[1], Qs, dP[0], dP[1], lane);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const f32x4 lq4 = *reinterpret_cast<const f32x4*>(&lse_s[16 * (2 * hh + tt) + 4 * g]);
+                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(&del_s[16 * (2 * hh + tt) + 4 * g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float p = fast_exp2(fmaf(S[mt][tt][r], sl2, -lq4[r]));
+                        if constexpr (!PLAIN) p = kvalid[mt] ? p : 0.f;
+                        S[mt][tt][r] = p;                            // P
+                        dP[mt][tt][r] = p * (dP[mt][tt][r] - dl4[r]);  // dS / scale
+                    }
+            }
+            mma_tr_pair<T, D>(adv[0], adv[1], dOs, hh, S[0][0], S[0][1], S[1][0], S[1][1], lane);
+            mma_tr_pair<T, D>(adk[0], adk[1], Qs, hh, dP[0][0], dP[0][1], dP[1][0], dP[1][1], lane);
+        }
     }
 #undef DKV_LOAD
 #pragma unroll
@@ -535,7 +560,7 @@ __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DKV_WPE
             const int64_t off = b * sh.kv_bs + (int64_t)krow[mt] * sh.kv_ls + (int64_t)h * D;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) {
-                store4T<T>(dk + off + dt * 16 + 4 * g, adk[mt][dt]);
+                store4T<T>(dk + off + dt * 16 + 4 * g, adk[mt][dt] * sh.scale);
                 store4T<T>(dv + off + dt * 16 + 4 * g, adv[mt][dt]);
             }
         }
@@ -583,8 +608,16 @@ extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* 
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d)};
     const dim3 grid((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
-    DISPATCH_ATTN(dtype, d, hipLaunchKernelGGL((attn_fwd_kernel<T, D>), grid, dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, key_mask, sh));
+    const bool plain = !key_mask && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
+#define FWD_LAUNCH(PL) hipLaunchKernelGGL((attn_fwd_kernel<T, D, PL>), grid, dim3(256), 0, (hipStream_t)stream,       \
+                                          (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, key_mask, sh)
+    DISPATCH_ATTN(dtype, d, {
+        if constexpr (sizeof(T) == 2) {
+            if (plain) FWD_LAUNCH(true);
+            else FWD_LAUNCH(false);
+        } else FWD_LAUNCH(false);
+    });
+#undef FWD_LAUNCH
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
@@ -607,12 +640,25 @@ extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const 
         hipLaunchKernelGGL((attn_delta_kernel<float>), dim3(sedd_grid_for(rows * 8, 256, 256 * 16)), dim3(256), 0, st,
                            (const float*)o, (const float*)dout, delta, B, H, Lq, d, o_bs, o_ls);
     const dim3 gq((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H), gk((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
+    const bool plain_q = !key_mask && Lk % TILE == 0, plain_k = !key_mask && Lk % OWN_PER_BLOCK == 0;
+#define DQ_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, PL>), gq, dim3(256), 0, st, (const T*)q,           \
+                                         (const T*)k, (const T*)v, (const T*)dout, lse, delta, key_mask, (T*)dq, sh)
+#define DKV_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, PL>), gk, dim3(256), 0, st, (const T*)q,         \
+                                          (const T*)k, (const T*)v, (const T*)dout, lse, delta, key_mask, (T*)dk,     \
+                                          (T*)dv, sh)
     DISPATCH_ATTN(dtype, d, {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D>), gq, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
-                           (const T*)dout, lse, delta, key_mask, (T*)dq, sh);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D>), gk, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
-                           (const T*)dout, lse, delta, key_mask, (T*)dk, (T*)dv, sh);
+        if constexpr (sizeof(T) == 2) {
+            if (plain_q) DQ_LAUNCH(true);
+            else DQ_LAUNCH(false);
+            if (plain_k) DKV_LAUNCH(true);
+            else DKV_LAUNCH(false);
+        } else {
+            DQ_LAUNCH(false);
+            DKV_LAUNCH(false);
+        }
     });
+#undef DQ_LAUNCH
+#undef DKV_LAUNCH
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
