@@ -5,7 +5,9 @@
 #include "common.h"
 
 #define TPB 256
-#define CHUNK_ROWS 32  // rows per backward chunk (never straddles a batch element)
+// rows per backward chunk (never straddles a batch element): 32, or 64 once there are enough rows to fill the chip
+// with the longer chunks (fewer block prologues / partial-sum folds per byte)
+__host__ __device__ static inline int chunk_rows(int64_t M) { return M >= 16384 ? 64 : 32; }
 
 // ---- 4-wide vector access helpers -------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float4 load4(const T* p);
@@ -110,7 +112,10 @@ extern "C" int sedd_ln_modulate_fwd(const float* x, const float* w, const float*
     const dim3 grid((unsigned)((M + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(mod_dtype, TM, DISPATCH_DT(out_dtype, TO, {
-        if (D <= 1024)
+        if (D <= 768)
+            hipLaunchKernelGGL((ln_mod_fwd_kernel<TM, TO, 3>), grid, dim3(TPB), 0, st, x, w, bias, (const TM*)shift,
+                               (const TM*)scale, mod_stride, (TO*)y, mean, rstd, M, L, D);
+        else if (D <= 1024)
             hipLaunchKernelGGL((ln_mod_fwd_kernel<TM, TO, 4>), grid, dim3(TPB), 0, st, x, w, bias, (const TM*)shift,
                                (const TM*)scale, mod_stride, (TO*)y, mean, rstd, M, L, D);
         else
@@ -126,7 +131,7 @@ extern "C" int sedd_ln_modulate_fwd(const float* x, const float* w, const float*
 // dw += dy*(1+sc)*xhat ; dsh += dy ; dsc += dy*xhat*w.  One block per chunk of <= 32 rows of one batch element.
 extern "C" int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L) {
     if (L <= 0 || M <= 0) return 0;
-    return (M / L) * ((L + CHUNK_ROWS - 1) / CHUNK_ROWS);
+    return (M / L) * ((L + chunk_rows(M) - 1) / chunk_rows(M));
 }
 
 template <typename TD, typename TM, int NV>
@@ -135,12 +140,12 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                                                          int64_t mod_stride, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* dx,
                                                          const float* dx_add, float* __restrict__ ws, int64_t nchunk,
-                                                         int64_t L, int D) {
+                                                         int64_t L, int D, int CR) {
     __shared__ float red[3 * NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t cpb = (L + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CHUNK_ROWS;
-    const int nrows = (int)((L - c0) < CHUNK_ROWS ? (L - c0) : CHUNK_ROWS);
+    const int64_t cpb = (L + CR - 1) / CR;
+    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;
+    const int nrows = (int)((L - c0) < CR ? (L - c0) : CR);
     float4 ww[NV], sc1[NV], aw[NV], ash[NV], asc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -151,16 +156,37 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
         sc1[k] = make_float4(1.f + s.x, 1.f + s.y, 1.f + s.z, 1.f + s.w);
         aw[k] = ash[k] = asc[k] = f4(0.f);
     }
+    // Rows are software-pipelined: the loads of this wave's next row (dy, x, the residual gradient, mean / rstd) are
+    // issued before the current row's two wave reductions, so a wave keeps two rows of HBM traffic in flight.
+    // (dx_add may alias dx: a row is read and then written by the same wave, and rows are disjoint between waves.)
+    float4 dA[NV], xA[NV], pA[NV];
+    float muA = 0.f, rsA = 0.f;
+#define LN_BWD_LOAD(r_, d_, x_, p_, mu_, rs_)                                                        \
+    do {                                                                                             \
+        const int64_t row_ = b * L + c0 + (r_);                                                      \
+        mu_ = mean[row_]; rs_ = rstd[row_];                                                          \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                             \
+            const int c = k * 256 + lane * 4;                                                        \
+            d_[k] = f4(0.f); x_[k] = f4(mu_); p_[k] = f4(0.f);                                       \
+            if (c < D) {                                                                             \
+                d_[k] = load4<TD>(dy + row_ * D + c);                                                \
+                x_[k] = load4<float>(x + row_ * D + c);                                              \
+                if (dx_add) p_[k] = load4<float>(dx_add + row_ * D + c);                             \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+    if (wave < nrows) LN_BWD_LOAD(wave, dA, xA, pA, muA, rsA);
     for (int r = wave; r < nrows; r += TPB / 64) {
         const int64_t row = b * L + c0 + r;
-        const float mu = mean[row], rs = rstd[row];
+        float4 dB[NV], xB[NV], pB[NV];
+        float muB = 0.f, rsB = 0.f;
+        if (r + TPB / 64 < nrows) LN_BWD_LOAD(r + TPB / 64, dB, xB, pB, muB, rsB);
+        const float mu = muA, rs = rsA;
         float4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int c = k * 256 + lane * 4;
-            float4 d = f4(0.f), xv = f4(mu);
-            if (c < D) { d = load4<TD>(dy + row * D + c); xv = load4<float>(x + row * D + c); }
+            const float4 d = dA[k], xv = xA[k];
             xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
             g[k] = make_float4(d.x * ww[k].x * sc1[k].x, d.y * ww[k].y * sc1[k].y, d.z * ww[k].z * sc1[k].z,
                                d.w * ww[k].w * sc1[k].w);
@@ -179,15 +205,15 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
             if (c < D) {
                 float4 o = make_float4(rs * (g[k].x - c1 - xh[k].x * c2), rs * (g[k].y - c1 - xh[k].y * c2),
                                        rs * (g[k].z - c1 - xh[k].z * c2), rs * (g[k].w - c1 - xh[k].w * c2));
-                float* dp = dx + row * D + c;
-                if (dx_add) {  // (dx_add may be dx itself: in-place accumulation)
-                    const float4 p = load4<float>(dx_add + row * D + c);
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-                }
-                store4<float>(dp, o);
+                if (dx_add) { o.x += pA[k].x; o.y += pA[k].y; o.z += pA[k].z; o.w += pA[k].w; }
+                store4<float>(dx + row * D + c, o);
             }
         }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { dA[k] = dB[k]; xA[k] = xB[k]; pA[k] = pB[k]; }
+        muA = muB; rsA = rsB;
     }
+#undef LN_BWD_LOAD
     // fold the 4 waves' column partials through LDS (wave by wave: deterministic order)
     for (int wv = 0; wv < TPB / 64; ++wv) {
         if (wave == wv) {
@@ -232,12 +258,15 @@ extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_DT(dy_dtype, TD, DISPATCH_DT(mod_dtype, TM, {
-        if (D <= 1024)
+        if (D <= 768)
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 3>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
+        else if (D <= 1024)
             hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 4>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D);
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
         else
             hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 8>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D);
+                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
     }));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
@@ -349,12 +378,12 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
                                                            const uint8_t* __restrict__ keep, float inv_keep,
                                                            uint64_t seed, uint32_t thr16,
                                                            TA* __restrict__ da, float* __restrict__ ws, int64_t L,
-                                                           int D) {
+                                                           int D, int CR) {
     __shared__ float red[(TPB / 64) * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t cpb = (L + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CHUNK_ROWS;
-    const int nrows = (int)((L - c0) < CHUNK_ROWS ? (L - c0) : CHUNK_ROWS);
+    const int64_t cpb = (L + CR - 1) / CR;
+    const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;
+    const int nrows = (int)((L - c0) < CR ? (L - c0) : CR);
     for (int cb = 0; cb < D; cb += 256) {  // 256-column slabs
         const int c = cb + lane * 4;
         float4 acc = f4(0.f);
@@ -407,7 +436,8 @@ extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dt
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
     DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
         hipLaunchKernelGGL((gate_res_bwd_kernel<TA, TM>), dim3((unsigned)nchunk), dim3(TPB), 0, (hipStream_t)stream,
-                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, (TA*)da, ws, L, D)));
+                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, (TA*)da, ws, L, D,
+                           chunk_rows(M))));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

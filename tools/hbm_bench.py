@@ -63,3 +63,12 @@ big = torch.randn(M, 3072, device=dev).bfloat16()
 ms = timeit(lambda: ops.transpose(big)); report("transpose [32768,3072] bf16", 2 * big.numel() * 2, ms)
 ms = timeit(lambda: ops.colsum(big)); report("colsum [32768,3072] bf16", big.numel() * 2, ms)
 ms = timeit(lambda: ops.gelu_bwd(big, big)); report("gelu_bwd [32768,3072] bf16", 3 * big.numel() * 2, ms)
+# backward elementwise (cfg-2 size)
+dyb = torch.randn(B, Ln, D, device=dev).bfloat16()
+_, mean, rstd = ops.ln_modulate_fwd(x, w, shift=mod[:, :D], scale=mod[:, D:2*D], out_dtype=torch.bfloat16)
+dxo, dxa = torch.empty_like(x), torch.randn_like(x)
+dw = torch.zeros(D, device=dev); dmod = torch.empty(B, 6 * D, device=dev)
+ms = timeit(lambda: ops.ln_modulate_bwd(dyb, x, w, mod[:, D:2*D], mean, rstd, dxo, dxa, dw, dmod[:, :D], dmod[:, D:2*D]))
+report("ln_modulate_bwd (+reduce) dy bf16, dx += add", M * D * 14, ms)
+ms = timeit(lambda: ops.gate_residual_bwd(dxa, a, mod[:, 2*D:3*D], dmod[:, 2*D:3*D], None, 1.0))
+report("gate_residual_bwd (+reduce)", M * D * 8, ms)
