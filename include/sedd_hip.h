@@ -181,6 +181,18 @@ int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
 int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                        int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
+/* Data gradient of nn.Linear against the weight AS STORED (dX = dY W with W [out_features, in_features] row-major; the
+ * reference gets it from torch.nn.functional.linear's backward, e.g. for transformer.py:125-133's Linears):
+ * C[M,N] = A[M,K] * B[K,N] (+ bias[N] for SEDD_EPI_BIAS) — "NN": B's reduction index is the row, so no transposed
+ * weight copy is made.  bf16 in/out only; M >= 192, N >= 96, K % 32 == 0, N % 8 == 0, lda/ldb multiples of 8,
+ * 16-byte aligned bases; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then transpose + sedd_gemm_nt). */
+int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                 int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K, sedd_stream_t stream);
+/* sedd_gemm_nt_dgelu with B given as [K, N] (the second MLP weight as stored, transformer.py:132):
+ * C = (A[M,K] * B[K,N]) .* gelu_tanh'(pre[M,N]); colsum += column sums of C.  Same requirements as sedd_gemm_nn. */
+int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                       int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
+                       sedd_stream_t stream);
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
  * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no

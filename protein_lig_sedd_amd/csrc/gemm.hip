@@ -319,7 +319,12 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 // then aliases ring stage NST-1, which the next tile's prologue (stages 0..NST-2) leaves alone until after that tile's
 // first two barriers.  Measured equal to the 8-wave kernels within noise (the 3-deep ring has one K step of
 // look-ahead), so it is not the default.
-template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8>
+// NNB = true (with TN = false): C[M,N] = A[M,K] * B[K,N] — A as in the NT form, B with the reduction index as the row
+//   (a data gradient against the nn.Linear weight as stored, dX = dY W, no transposed weight copy).  B takes the TN
+//   path's stage layout and transposing reads, but A's fragments hold k = 8g..8g+7 in natural order, so lane group g
+//   addresses rows 8g+q and 8g+4+q instead, and the bank swizzle keys on row bits {0,1,3} (rows 8g+q, g = 0,1 of one
+//   half-wave must land in 8 distinct 32-byte bank groups).
+template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
@@ -349,7 +354,9 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     const int work = splitk > 1 ? xcd_remap(blockIdx.x, gridDim.x) : 0;
     const int64_t kbeg = (int64_t)(work / ntiles) * Kper;
     const int nkt = (int)((Ktot - kbeg < Kper ? Ktot - kbeg : Kper) / BIG_BK);
-    const int64_t ksA = TN ? BIG_BK * lda : BIG_BK, ksB = TN ? BIG_BK * ldb : BIG_BK;  // operand advance per K tile
+    constexpr bool TA = TN, TB = TN || NNB;  // which operand is stored with the reduction index as the row
+    static_assert(!(TN && NNB), "NNB refines the NT form");
+    const int64_t ksA = TA ? BIG_BK * lda : BIG_BK, ksB = TB ? BIG_BK * ldb : BIG_BK;  // operand advance per K tile
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&smem[0][0];
     // fragment read offsets: lane -> row (lane & 15) of a 16-row fragment, k chunk (lane >> 4), swizzled
     const int r15 = lane & 15;
@@ -359,7 +366,8 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     constexpr int PB = BN_ * 2;  // bytes per B row in a TN stage
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, tyc = 4 * (tg & 1) + tq;
     const int ta = (4 * tg + tq) * 512 + (tp >> 1) * 16 + (tp & 1) * 8;
-    const int tb = ASLOTS * 16 + (4 * tg + tq) * PB + (tp >> 1) * 16 + (tp & 1) * 8;
+    const int tb = ASLOTS * 16 + ((NNB ? 8 : 4) * tg + tq) * PB + (tp >> 1) * 16 + (tp & 1) * 8;
+    constexpr int TB_HI = (NNB ? 4 : 16) * PB;  // second transposing read of a B fragment: rows +4 (natural k) / +16
     const bool vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!pre || (reinterpret_cast<uintptr_t>(pre) & 15) == 0);
     const bool staged = STAGED && splitk == 1 && !accumulate && (ldc * sizeof(TO)) % 16 == 0 &&
@@ -376,7 +384,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         m0 = (int64_t)(wg_ / ntn) * BIG_BM;                                                                          \
         n0 = (int64_t)(wg_ % ntn) * BN_;                                                                             \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
-            if constexpr (TN) { /* wave-instruction j = 2 token rows x 512 B */                                      \
+            if constexpr (TA) { /* wave-instruction j = 2 token rows x 512 B */                                      \
                 const int r = (i * NW + wave) * 2 + (lane >> 5);                                                      \
                 int64_t col = m0 + (((lane & 31) ^ (2 * (r & 7))) << 3);                                             \
                 col = col < M ? col : 0;                                                                             \
@@ -390,10 +398,11 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
             }                                                                                                        \
         }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                             \
-            if constexpr (TN) {                                                                                      \
+            if constexpr (TB) {                                                                                      \
                 constexpr int CPR = BN_ / 8; /* 16-byte chunks per B row */                                          \
                 const int r = (i * NW + wave) * (64 / CPR) + lane / CPR;                                              \
-                int64_t col = n0 + (((lane % CPR) ^ (2 * (r & 7))) << 3);                                            \
+                const int sw = NNB ? ((r & 3) | (((r >> 3) & 1) << 2)) : (r & 7);                                     \
+                int64_t col = n0 + (((lane % CPR) ^ (2 * sw)) << 3);                                                 \
                 col = col < N ? col : 0;                                                                             \
                 srcB[i] = B + (kbeg + r) * ldb + col;                                                                \
             } else {                                                                                                 \
@@ -422,7 +431,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #define BIG_READ_A(dst, st, mbase)                                                                                   \
     do {                                                                                                             \
         _Pragma("unroll") for (int m = 0; m < TMH; ++m) {                                                            \
-            if constexpr (TN) {                                                                                      \
+            if constexpr (TA) {                                                                                      \
                 const int o_ = ta + (((wm * TM + (mbase) + m) ^ tyc) << 5);                                          \
                 union { struct { s16x4 lo, hi; } s; bf16x8 v; } f_;                                                  \
                 f_.s.lo = BIG_TR(st, o_);                                                                            \
@@ -436,11 +445,11 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #define BIG_READ_B(set, st)                                                                                          \
     do {                                                                                                             \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                              \
-            if constexpr (TN) {                                                                                      \
+            if constexpr (TB) {                                                                                      \
                 const int o_ = tb + (((wn * 4 + n) ^ tyc) << 5);                                                     \
                 union { struct { s16x4 lo, hi; } s; bf16x8 v; } f_;                                                  \
                 f_.s.lo = BIG_TR(st, o_);                                                                            \
-                f_.s.hi = BIG_TR(st, o_ + 16 * PB);                                                                  \
+                f_.s.hi = BIG_TR(st, o_ + TB_HI);                                                                    \
                 b[set][n] = f_.v;                                                                                    \
             } else {                                                                                                 \
                 b[set][n] = *reinterpret_cast<const bf16x8*>(&smem[st][fb + n * 64]);                                \
@@ -846,15 +855,25 @@ static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
 
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                         int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
-                        int64_t K, float* colsum, sedd_stream_t stream) {
+                        int64_t K, float* colsum, sedd_stream_t stream, bool b_kn = false) {
     SEDD_CHECK_ARG((in_dtype == SEDD_F32 || in_dtype == SEDD_BF16) && (out_dtype == SEDD_F32 || out_dtype == SEDD_BF16),
                    "gemm_nt: bad dtype");
+    if (b_kn) {  // B given as [K, N] (NN form): bf16 big-tile kernel only
+        if (in_dtype != SEDD_BF16 || out_dtype != SEDD_BF16 || accumulate || K % BIG_BK || M < 192 || N < 96 || N % 8 ||
+            ldb % 8 || lda % 8 || ldb < N || lda < K || ldc < N || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
+            sedd_set_error("gemm_nn: unsupported operands (bf16 in/out; M >= 192, N >= 96, K %% 32, N %% 8, lda %% 8, "
+                           "ldb %% 8 must be 0, 16-byte aligned bases): M=%ld N=%ld K=%ld lda=%ld ldb=%ld", (long)M,
+                           (long)N, (long)K, (long)lda, (long)ldb);
+            return SEDD_ERR_UNSUPPORTED_SHAPE;
+        }
+    }
     SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= EPI_DGELU, "gemm_nt: bad epilogue %d", epilogue);
     SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_nt: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == EPI_DGELU || bias, "gemm_nt: epilogue needs a bias");
     SEDD_CHECK_ARG(!accumulate || epilogue == SEDD_EPI_NONE, "gemm_nt: accumulate only with SEDD_EPI_NONE");
     const int kal = in_dtype == SEDD_BF16 ? 8 : 4;
-    if (K % kal || lda % kal || ldb % kal || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || lda < K || ldb < K || ldc < N) {
+    if (K % kal || lda % kal || ldb % kal || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || lda < K || (!b_kn && ldb < K) ||
+        ldc < N) {
         sedd_set_error("gemm_nt: K=%ld lda=%ld ldb=%ld ldc=%ld unsupported (K, lda, ldb must be multiples of %d, "
                        "16-byte aligned bases)", (long)K, (long)lda, (long)ldb, (long)ldc, kal);
         return SEDD_ERR_UNSUPPORTED_SHAPE;
@@ -867,7 +886,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == SEDD_BF16) {
         // big-tile path: 256 x 256 or 256 x 128 tiles, whichever quantises better onto the 256 CUs
-        const bool big_ok = K % BIG_BK == 0 && M >= 192 && N >= 96 && !getenv("SEDD_GEMM_SMALL_TILES");
+        const bool big_ok = K % BIG_BK == 0 && M >= 192 && N >= 96 && (b_kn || !getenv("SEDD_GEMM_SMALL_TILES"));
         if (epilogue == EPI_DGELU) {
             // only the big-tile kernel's staged bf16 epilogue implements it
             if (!big_ok || out_dtype != SEDD_BF16 || accumulate || (ldc * 2) % 16 || ((uintptr_t)C & 15) ||
@@ -897,7 +916,14 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \
                        (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum)
-            if (epilogue == EPI_DGELU && wide) {
+#define BIG_LAUNCH_X(BN_, DG_, NNB_)                                                                                 \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, BN_, 4, false, DG_, 8, NNB_>), g2, dim3(512), 0, st,            \
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre,   \
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum)
+            if (b_kn) {
+                if (epilogue == EPI_DGELU) { if (wide) BIG_LAUNCH_X(256, true, true); else BIG_LAUNCH_X(128, true, true); }
+                else { if (wide) BIG_LAUNCH_X(256, false, true); else BIG_LAUNCH_X(128, false, true); }
+            } else if (epilogue == EPI_DGELU && wide) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 256, 4, false, true>), g2, dim3(512), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
@@ -924,6 +950,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                 else BIG_LAUNCH(float, 128, 6);
             }
 #undef BIG_LAUNCH
+#undef BIG_LAUNCH_X
         } else if (K % BK16 == 0) {
             // split K across blockIdx.y for accumulating fp32 outputs with too few tiles to fill 256 CUs
             int splitk = 1;
@@ -978,6 +1005,25 @@ extern "C" int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int
     SEDD_CHECK_ARG(pre, "gemm_nt_dgelu: pre is null");
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
                         K, colsum, stream);
+}
+
+// C[M,N] = A[M,K] * B[K,N] (bf16): the data gradient of nn.Linear against the weight as stored (dX = dY W, W [out, in]),
+// no transposed weight copy.  epilogue: SEDD_EPI_NONE or SEDD_EPI_BIAS.
+extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                            int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K,
+                            sedd_stream_t stream) {
+    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == SEDD_EPI_BIAS, "gemm_nn: bad epilogue %d", epilogue);
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, nullptr, 0, M, N, K, nullptr, stream,
+                        true);
+}
+
+// sedd_gemm_nt_dgelu with B given as [K, N]: dU = (dY W2) .* gelu'(U), colsum += column sums, W2 [out, hidden] as stored
+extern "C" int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                  int in_dtype, int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N,
+                                  int64_t K, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(pre, "gemm_nn_dgelu: pre is null");
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
+                        K, colsum, stream, true);
 }
 
 // C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations

@@ -6,6 +6,8 @@ saved-activation bookkeeping that torch.autograd would otherwise do.  Gradient c
 a `.grad` tensor (the trainer pre-allocates them as views of one flat buffer) weight gradients are ACCUMULATED into
 it in place by the producing kernel and autograd receives None; otherwise a fresh gradient tensor is returned.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -88,6 +90,9 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
             db = ops.colsum(dy2d)
     dx = None
     if need_dx:
+        Wc = compute_weight(W, dy2d.dtype)                        # [N, K] as stored
+        if dx_dtype in (None, dy2d.dtype) and ops.gemm_nn_supported(dy2d, Wc):
+            return ops.gemm_nn(dy2d, Wc), dW, db                  # dX = dY W, no transposed weight copy
         Wt = compute_weight(W, dy2d.dtype, transposed=True)      # [K, Np]
         if Wt.shape[1] != dy2d.shape[1] or dy2d.stride(0) % align:  # ragged out-feature dim (e.g. V = 26): pad dy
             dyp = torch.zeros(dy2d.shape[0], Wt.shape[1], dtype=dy2d.dtype, device=dy2d.device)
@@ -100,6 +105,16 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
 def mlp_out_bwd(g2d, u2d, dy2d, W2, b2, b1):
     """backward of `y = Linear2(GELU(u))` down to du: -> (du, dW2, db2, db1).  The data gradient, GELU's derivative and
     the first Linear's bias gradient (column sums of du) are one GEMM launch when the shapes allow."""
+    W2c = compute_weight(W2, dy2d.dtype)
+    if (ops.gemm_nn_supported(dy2d, W2c) and u2d.dtype == torch.bfloat16 and u2d.is_contiguous()
+            and u2d.data_ptr() % 16 == 0 and not os.environ.get("SEDD_NO_DGELU")):
+        _, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2, need_dx=False)
+        bs = _sink(b1)
+        db1 = None
+        if bs is None:
+            bs = db1 = torch.zeros(u2d.shape[1], dtype=torch.float32, device=u2d.device)
+        du = ops.gemm_nn_dgelu(dy2d, W2c, u2d, colsum=bs)
+        return du, dW2, db2, db1
     W2t = compute_weight(W2, dy2d.dtype, transposed=True)
     if W2t.shape[1] == dy2d.shape[1] and ops.gemm_nt_dgelu_supported(dy2d, W2t, u2d):
         _, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2, need_dx=False)

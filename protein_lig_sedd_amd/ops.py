@@ -431,6 +431,45 @@ def gemm_nt_dgelu(A, B, pre, colsum=None):
     return out
 
 
+def gemm_nn_supported(A, B):
+    """whether sedd_gemm_nn / sedd_gemm_nn_dgelu take A [M, K] @ B [K, N] (else: transposed copy of B + gemm_nt)."""
+    if os.environ.get("SEDD_NO_GEMM_NN"):
+        return False
+    M, K = A.shape
+    N = B.shape[1]
+    return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and M >= 192 and N >= 96 and N % 8 == 0
+            and K % 32 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nn(A, B, bias=None, out=None):
+    """C[M,N] = A[M,K] @ B[K,N] (+bias), bf16: the data gradient dY @ W against the weight as stored."""
+    M, K = A.shape
+    K2, N = B.shape
+    if K != K2:
+        raise ValueError(f"gemm_nn: A {tuple(A.shape)} vs B {tuple(B.shape)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    epi = _L.EPI_NONE if bias is None else _L.EPI_BIAS
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_nn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                 _p(bias), epi, M, N, K, _stream()), "sedd_gemm_nn")
+    return out
+
+
+def gemm_nn_dgelu(A, B, pre, colsum=None):
+    """C = (A[M,K] @ B[K,N]) * gelu_tanh'(pre[M,N]) (bf16); colsum fp32 [N] += C.sum(0) when given."""
+    M, K = A.shape
+    N = B.shape[1]
+    if pre.shape != (M, N) or B.shape[0] != K:
+        raise ValueError(f"gemm_nn_dgelu: A {tuple(A.shape)} B {tuple(B.shape)} pre {tuple(pre.shape)}")
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_nn_dgelu(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                       _p(pre), _p(colsum), M, N, K, _stream()), "sedd_gemm_nn_dgelu")
+    return out
+
+
 def gemm_tn_supported(A, B):
     """whether sedd_gemm_tn takes these operands (else: transpose + gemm_nt)."""
     K, M = A.shape

@@ -70,7 +70,8 @@ def test_argument_validation_without_gpu():
     assert b"multiples of 8" in L.sedd_last_error()
     assert L.sedd_attn_fwd(p, p, p, p, p, None, 1, 1, 1, 4, 4, 48, 48, 48, 48, 48, 48, 48, None) == -2
     assert L.sedd_ln_modulate_fwd(p, p, None, None, None, 0, 0, p, 0, None, None, 4, 2, 4100, None) == -2
-    assert L.sedd_ln_bwd_chunks(64 * 512, 512) == 64 * 16
+    assert L.sedd_ln_bwd_chunks(64 * 512, 512) == 64 * 8   # 64-row chunks from 16384 rows up
+    assert L.sedd_ln_bwd_chunks(4 * 512, 512) == 4 * 16     # 32-row chunks below
     assert L.sedd_ln_bwd_chunks(10 * 33, 33) == 10 * 2
 
 

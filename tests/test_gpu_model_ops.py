@@ -110,6 +110,50 @@ def test_gemm_nt_dgelu(M, N, K):
     assert rel_err(out.float(), pf.grad) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 2304), (4096, 768, 768), (300, 136, 96), (1024, 3072, 768), (256, 1000, 64)])
+def test_gemm_nn_bf16(M, N, K):
+    """C = A[M,K] @ B[K,N] with B as stored (data gradient dY @ W) == the NT GEMM on a transposed copy of B."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    A = (0.3 * torch.randn(M, K, device=DEV)).bfloat16()
+    B = (0.3 * torch.randn(K, N, device=DEV)).bfloat16()
+    assert ops.gemm_nn_supported(A, B)
+    out = ops.gemm_nn(A, B)
+    ref = ops.gemm_nt(A, B.t().contiguous())
+    assert rel_err(out.float(), ref.float()) < 2e-3  # (same products, another summation order over k)
+    assert rel_err(out.float(), (A.double() @ B.double()).float()) < 1e-2
+    bias = torch.randn(N, device=DEV)
+    assert rel_err(ops.gemm_nn(A, B, bias=bias).float(), ref.float() + bias) < 1e-2
+    # strided operands (row stride > extent)
+    Ab = torch.zeros(M, K + 64, device=DEV).bfloat16(); Ab[:, :K] = A
+    Bb = torch.zeros(K, N + 8, device=DEV).bfloat16(); Bb[:, :N] = B
+    assert torch.equal(ops.gemm_nn(Ab[:, :K], Bb[:, :N]), out)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 3072, 768), (1024, 384, 96), (320, 1000, 64)])
+def test_gemm_nn_dgelu(M, N, K):
+    ops = _ops()
+    torch.manual_seed(M + N + K + 1)
+    A = (0.3 * torch.randn(M, K, device=DEV)).bfloat16()
+    B = (0.3 * torch.randn(K, N, device=DEV)).bfloat16()
+    pre = torch.randn(M, N, device=DEV).bfloat16()
+    cs = torch.ones(N, device=DEV)
+    out = ops.gemm_nn_dgelu(A, B, pre, colsum=cs)
+    cs2 = torch.ones(N, device=DEV)
+    ref = ops.gemm_nt_dgelu(A, B.t().contiguous(), pre, colsum=cs2)
+    assert rel_err(out.float(), ref.float()) < 2e-3
+    assert rel_err(cs, cs2) < 1e-3
+
+
+def test_gemm_nn_rejects_unsupported():
+    ops = _ops()
+    from protein_lig_sedd_amd._lib import SeddError
+    A = torch.zeros(512, 32, device=DEV).bfloat16()
+    assert not ops.gemm_nn_supported(A, torch.zeros(32, 26, device=DEV).bfloat16())
+    with pytest.raises(SeddError):
+        ops.gemm_nn(A, torch.zeros(32, 104, device=DEV).bfloat16()[:, :100])
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     from protein_lig_sedd_amd._lib import SeddError
