@@ -217,11 +217,14 @@ int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
 int sedd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* key_mask,
                   int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
                   int64_t kv_ls, int64_t o_bs, int64_t o_ls, sedd_stream_t stream);
-/* backward: dq/dk/dv written with the strides of q/k/v; delta fp32 [B, H, Lq] is caller workspace. */
+/* backward: dq/dk/dv written with the strides of q/k/v; delta fp32 [B, H, Lq] is caller workspace.
+ * rot_cos / rot_sin (both NULL or both fp32 [L, d/2], Lq == Lk == L): additionally apply the gradient of
+ * apply_rotary_pos_emb (rotary.py:42-51; the conjugate rotation) to dq and dk as they are written, i.e. the result is
+ * the gradient w.r.t. the PRE-rotary q and k — what sedd_rotary_qkv(conj = 1) would make of the plain output. */
 int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                  const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta, int dtype, int B, int H,
-                  int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs,
-                  int64_t o_ls, sedd_stream_t stream);
+                  const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta, int dtype, int B, int H, int Lq,
+                  int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls,
+                  const float* rot_cos, const float* rot_sin, sedd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------- optimiser / EMA
  * One pass over the flat fp32 parameter buffer: gradient clip coefficient (losses.py:65-66) -> AdamW

@@ -52,7 +52,7 @@ SIGNATURES = {
     "sedd_gemm_nn": "plplpliipilllp",
     "sedd_gemm_nn_dgelu": "plplpliipplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
-    "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "p",
+    "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "i" + "f" + "lp",
     "sedd_sumsq_clip": "plffppp",
     "sedd_ema_update": "ppflp",

@@ -222,10 +222,40 @@ template <> __device__ __forceinline__ void store4T<bf16_t>(bf16_t* p, f32x4 v) 
     *reinterpret_cast<uint2*>(p) = c.u;
 }
 
+// Write one own row's gradient (acc * mul, rounded to T like the unfused kernels' output), optionally through the
+// CONJUGATE rotary rotation of rotary.py:42-51's backward (cs / sn = this position's [D/2] table rows, or null): the
+// pair (j, j + D/2) of a NeoX-halves rotation lives in fragments dt and dt + D/32 of the same lane.
+template <typename T, int D>
+__device__ __forceinline__ void store_row_rot(T* row, const f32x4 (&acc)[D / 16], float mul, const float* cs,
+                                              const float* sn, int g) {
+    if (!cs) {
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) store4T<T>(row + dt * 16 + 4 * g, acc[dt] * mul);
+        return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+        const float4 c = *reinterpret_cast<const float4*>(cs + dt * 16 + 4 * g);
+        const float4 sv = *reinterpret_cast<const float4*>(sn + dt * 16 + 4 * g);
+        const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {-sv.x, -sv.y, -sv.z, -sv.w};
+        f32x4 lo = acc[dt] * mul, hi = acc[dt + D / 32] * mul, olo, ohi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x1 = sizeof(T) == 2 ? (float)(T)lo[r] : lo[r], x2 = sizeof(T) == 2 ? (float)(T)hi[r] : hi[r];
+            olo[r] = x1 * cc[r] - x2 * ss[r];
+            ohi[r] = x2 * cc[r] + x1 * ss[r];
+        }
+        store4T<T>(row + dt * 16 + 4 * g, olo);
+        store4T<T>(row + D / 2 + dt * 16 + 4 * g, ohi);
+    }
+}
+
 struct AttnShape {
     int H, Lq, Lk;
     int64_t q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls;
     float scale;
+    const float* rot_cos;  // backward only: conjugate rotary on dQ / dK ([L, D/2] fp32 tables), or null
+    const float* rot_sin;
 };
 
 // ==================================================================================================== forward
@@ -456,8 +486,8 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     for (int mt = 0; mt < 2; ++mt)
         if (qrow[mt] < sh.Lq) {
             T* row = dq + b * sh.q_bs + (int64_t)qrow[mt] * sh.q_ls + (int64_t)h * D;
-#pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(row + dt * 16 + 4 * g, acc[mt][dt] * sh.scale);
+            const int64_t ro = (int64_t)qrow[mt] * (D / 2);
+            store_row_rot<T, D>(row, acc[mt], sh.scale, sh.rot_cos ? sh.rot_cos + ro : nullptr, sh.rot_sin + ro, g);
         }
 }
 
@@ -558,11 +588,10 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
     for (int mt = 0; mt < 2; ++mt)
         if (krow[mt] < sh.Lk) {
             const int64_t off = b * sh.kv_bs + (int64_t)krow[mt] * sh.kv_ls + (int64_t)h * D;
+            const int64_t ro = (int64_t)krow[mt] * (D / 2);
+            store_row_rot<T, D>(dk + off, adk[mt], sh.scale, sh.rot_cos ? sh.rot_cos + ro : nullptr, sh.rot_sin + ro, g);
 #pragma unroll
-            for (int dt = 0; dt < D / 16; ++dt) {
-                store4T<T>(dk + off + dt * 16 + 4 * g, adk[mt][dt] * sh.scale);
-                store4T<T>(dv + off + dt * 16 + 4 * g, adv[mt][dt]);
-            }
+            for (int dt = 0; dt < D / 16; ++dt) store4T<T>(dv + off + dt * 16 + 4 * g, adv[mt][dt]);
         }
 }
 
@@ -606,7 +635,7 @@ extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (rc) return rc;
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
-    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d)};
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr};
     const dim3 grid((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
     const bool plain = !key_mask && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
 #define FWD_LAUNCH(PL) hipLaunchKernelGGL((attn_fwd_kernel<T, D, PL>), grid, dim3(256), 0, (hipStream_t)stream,       \
@@ -625,12 +654,15 @@ extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* 
 extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                              const float* lse, const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta,
                              int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
-                             int64_t kv_ls, int64_t o_bs, int64_t o_ls, sedd_stream_t stream) {
+                             int64_t kv_ls, int64_t o_bs, int64_t o_ls, const float* rot_cos, const float* rot_sin,
+                             sedd_stream_t stream) {
     int rc = check_attn("attn_bwd", dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls);
     if (rc) return rc;
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "attn_bwd: null pointer");
-    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d)};
+    SEDD_CHECK_ARG((rot_cos == nullptr) == (rot_sin == nullptr), "attn_bwd: rot_cos and rot_sin go together");
+    SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin};
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * H * Lq;
     if (dtype == SEDD_BF16)

@@ -212,8 +212,7 @@ def ddit_block_backward(dx2, st, P, n_heads):
     qkv = st["qkv"]
     dqkv = torch.empty_like(qkv)
     ops.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], st["o"], do.view(B, L, H, d), st["lse"], dqkv[:, :, 0],
-                 dqkv[:, :, 1], dqkv[:, :, 2])
-    ops.rotary_qkv_(dqkv, st["cos"], st["sin"], conj=True)
+                 dqkv[:, :, 1], dqkv[:, :, 2], rotary=(st["cos"], st["sin"]))  # rotary's gradient fused into the stores
     dh1, grads["attn_qkv.weight"], _ = linear_bwd(st["h1"].view(M, D), dqkv.view(M, 3 * D), P["attn_qkv.weight"])
     dw1, grads["norm1.weight"] = _vec_sink(P["norm1.weight"], D)
     ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],

@@ -535,8 +535,10 @@ def attn_fwd(q, k, v, key_mask=None, out=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None):
-    """dq/dk/dv: preallocated views with the same strides as q/k/v (e.g. slots of a packed dqkv)."""
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None, rotary=None):
+    """dq/dk/dv: preallocated views with the same strides as q/k/v (e.g. slots of a packed dqkv).
+    rotary = (cos, sin) compact fp32 [L, d/2] tables: dq / dk come out as gradients of the PRE-rotary q / k (the
+    conjugate rotation of rotary_qkv_(conj=True) applied as they are written)."""
     B, Lq, H, d = q.shape
     Lk = k.shape[1]
     qs, ks = _attn_strides(q), _attn_strides(k)
@@ -546,10 +548,14 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None):
         raise ValueError("dout must be laid out like o")
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     km = None if key_mask is None else _c(key_mask.to(torch.uint8))
+    rc, rs = rotary if rotary is not None else (None, None)
+    if rc is not None and (rc.shape != (Lq, d // 2) or rs.shape != rc.shape or rc.dtype != torch.float32
+                           or not rc.is_contiguous() or not rs.is_contiguous() or Lq != Lk):
+        raise ValueError("attn_bwd: rotary tables must be contiguous fp32 [L, d/2] with Lq == Lk == L")
     with _Timed("attn_bwd", 10.0 * B * H * Lq * Lk * d):
         check(lib().sedd_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(km), _p(dq), _p(dk), _p(dv),
                                   _p(delta), _dt(q), B, H, Lq, Lk, d, qs[0], qs[1], ks[0], ks[1], o.stride(0),
-                                  o.stride(1), _stream()), "sedd_attn_bwd")
+                                  o.stride(1), _p(rc), _p(rs), _stream()), "sedd_attn_bwd")
 
 
 # ------------------------------------------------------------------------------------------ optimiser

@@ -388,6 +388,28 @@ def test_attention_packed_qkv_and_spike():
     assert rel_err(dqkv, qr.grad) < 2e-2
 
 
+@pytest.mark.parametrize("dtype,B,L,H,d", [(torch.bfloat16, 2, 256, 4, 64), (torch.bfloat16, 1, 200, 2, 32),
+                                           (torch.float32, 1, 96, 2, 96), (torch.bfloat16, 1, 128, 1, 128)])
+def test_attention_backward_fused_rotary_gradient(dtype, B, L, H, d):
+    """attn_bwd(rotary=(cos, sin)) == attn_bwd followed by rotary_qkv_(conj=True) (rotary.py:42-51's gradient)."""
+    ops = _ops()
+    torch.manual_seed(d + L)
+    x = torch.randn(B, L, 3, H, d, device=DEV).to(dtype)
+    dout = torch.randn(B, L, H, d, device=DEV).to(dtype)
+    ang = torch.rand(L, d // 2, device=DEV) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    o, lse = ops.attn_fwd(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+    ref = torch.empty_like(x)
+    ops.attn_bwd(x[:, :, 0], x[:, :, 1], x[:, :, 2], o, dout, lse, ref[:, :, 0], ref[:, :, 1], ref[:, :, 2])
+    ops.rotary_qkv_(ref, cos, sin, conj=True)
+    got = torch.empty_like(x)
+    ops.attn_bwd(x[:, :, 0], x[:, :, 1], x[:, :, 2], o, dout, lse, got[:, :, 0], got[:, :, 1], got[:, :, 2],
+                 rotary=(cos, sin))
+    assert torch.equal(got[:, :, 2], ref[:, :, 2])
+    # same fp32 arithmetic on the same rounded inputs; fma contraction may differ by an ulp of the output type
+    assert rel_err(got.float(), ref.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
 def test_optimizer_kernels():
     ops = _ops()
     torch.manual_seed(7)
