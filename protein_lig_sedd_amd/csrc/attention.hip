@@ -14,7 +14,7 @@
 //
 // The fp32 instantiation (exact v_mfma_f32_16x16x4_f32) exists for the fp32 parity configuration and the
 // fp32-autocast cross model.  Backward is two deterministic kernels (dQ per query block, dK/dV per key block; no
-// atomics); delta = rowsum(dO * O) comes from a small pre-pass.
+// atomics); delta = rowsum(dO * O) is computed by the dQ kernel for its own queries and handed to the dK/dV kernel.
 // MFMA-bound: forward 4*B*H*Lq*Lk*d flop, backward 14*B*H*Lq*Lk*d (7 products incl. the recomputed S and dP).
 #include "common.h"
 
@@ -369,44 +369,13 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     }
 }
 
-// ============================================================================================ delta pre-pass
-// 8 lanes per (b, q, h) row, each lane d/8 contiguous elements in 4-element vector loads; xor-shuffle reduce.
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 ld4(const bf16_t* p) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
-    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-                       __uint_as_float(r.y & 0xffff0000u));
-}
-template <typename T>
-__global__ void __launch_bounds__(256) attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int H, int Lq, int D,
-                                                         int64_t o_bs, int64_t o_ls) {
-    const int64_t total = (int64_t)B * Lq * H;
-    const int sub = threadIdx.x & 7, per = D / 8;
-    for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; idx < total; idx += ((int64_t)gridDim.x * 256) >> 3) {
-        const int h = (int)(idx % H);
-        const int qi = (int)((idx / H) % Lq);
-        const int b = (int)(idx / ((int64_t)Lq * H));
-        const int64_t off = b * o_bs + (int64_t)qi * o_ls + (int64_t)h * D + sub * per;
-        float s = 0.f;
-        for (int d = 0; d < per; d += 4) {
-            const float4 x = ld4(o + off + d), y = ld4(dout + off + d);
-            s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if (sub == 0) delta[((int64_t)b * H + h) * Lq + qi] = s;
-    }
-}
-
 // ================================================================================================ dQ kernel
 // The softmax scale of dS = P (dP - delta) * scale is applied once to the finished dQ / dK accumulators.
 template <typename T, int D, bool PLAIN>
 __global__ void __launch_bounds__(256) ATTN_WPE((wpe_if_small<T, D>(ATTN_DQ_WPE)))
 attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
-                   const T* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-                   const uint8_t* __restrict__ mask, T* __restrict__ dq, AttnShape sh) {
+                   const T* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ lse,
+                   float* __restrict__ delta, const uint8_t* __restrict__ mask, T* __restrict__ dq, AttnShape sh) {
     constexpr int LS = D + Op<T>::PAD;
     __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
     __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
@@ -430,7 +399,22 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
         dof[mt] = ok ? load_rowfrag<T, D>(dob + (int64_t)qrow[mt] * sh.o_ls, g) : zero_rowfrag<T, D>();
         const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (ok ? qrow[mt] : 0);
         lq[mt] = ok ? lse[si] * LOG2E : 0.f;
-        dl[mt] = ok ? delta[si] : 0.f;
+        // delta = rowsum(dO * O) of this query (flash-attention backward's D), from the dO fragment already in
+        // registers and the matching O fragment; also left in `delta` for the dK/dV kernel, which runs next
+        const RowFrag<T, D> of = ok ? load_rowfrag<T, D>(o + b * sh.o_bs + (int64_t)h * D + (int64_t)qrow[mt] * sh.o_ls, g)
+                                    : zero_rowfrag<T, D>();
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / Op<T>::KS; ++s) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf((float)dof[mt].v[s][j], (float)of.v[s][j], dsum);
+            } else dsum = fmaf(dof[mt].v[s], of.v[s], dsum);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        dl[mt] = dsum;
+        if (ok && g == 0) delta[si] = dsum;
     }
     f32x4 acc[2][D / 16];
 #pragma unroll
@@ -664,17 +648,11 @@ extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const 
     SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin};
     hipStream_t st = (hipStream_t)stream;
-    const int64_t rows = (int64_t)B * H * Lq;
-    if (dtype == SEDD_BF16)
-        hipLaunchKernelGGL((attn_delta_kernel<bf16_t>), dim3(sedd_grid_for(rows * 8, 256, 256 * 16)), dim3(256), 0, st,
-                           (const bf16_t*)o, (const bf16_t*)dout, delta, B, H, Lq, d, o_bs, o_ls);
-    else
-        hipLaunchKernelGGL((attn_delta_kernel<float>), dim3(sedd_grid_for(rows * 8, 256, 256 * 16)), dim3(256), 0, st,
-                           (const float*)o, (const float*)dout, delta, B, H, Lq, d, o_bs, o_ls);
     const dim3 gq((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H), gk((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
     const bool plain_q = !key_mask && Lk % TILE == 0, plain_k = !key_mask && Lk % OWN_PER_BLOCK == 0;
 #define DQ_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, PL>), gq, dim3(256), 0, st, (const T*)q,           \
-                                         (const T*)k, (const T*)v, (const T*)dout, lse, delta, key_mask, (T*)dq, sh)
+                                         (const T*)k, (const T*)v, (const T*)o, (const T*)dout, lse, delta, key_mask,  \
+                                         (T*)dq, sh)
 #define DKV_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, PL>), gk, dim3(256), 0, st, (const T*)q,         \
                                           (const T*)k, (const T*)v, (const T*)dout, lse, delta, key_mask, (T*)dk,     \
                                           (T*)dv, sh)
