@@ -128,12 +128,15 @@ int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, co
                            int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed, float p_drop,
                            float* out, int64_t M, int64_t L, int D, sedd_stream_t stream);
 /* backward: da = dout * gate_b * keep*inv_keep (a_dtype); per-chunk partial sums of dgate = sum_l dout*a*keep*inv
- * to ws fp32 [nchunk, D] (same chunking as sedd_ln_bwd_chunks), folded by sedd_gate_residual_bwd_reduce. */
+ * to ws fp32 [nchunk, D] (same chunking as sedd_ln_bwd_chunks), folded by sedd_gate_residual_bwd_reduce.
+ * want_colsum != 0: ws is [2, nchunk, D] and its second plane receives the partial column sums of da (as stored),
+ * which the reduce call adds into dbias fp32 [D] (+=): the bias gradient of the Linear that produced `a`
+ * (torch.nn.functional.linear's backward for e.g. transformer.py:132), without a separate pass over da. */
 int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
                            int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed, float p_drop,
-                           void* da, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
-int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L, int D,
-                                  sedd_stream_t stream);
+                           void* da, float* ws, int want_colsum, int64_t M, int64_t L, int D, sedd_stream_t stream);
+int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, float* dbias, int64_t M,
+                                  int64_t L, int D, sedd_stream_t stream);
 
 /* Rotary (model/rotary.py:13-51): in-place NeoX rotation of the Q and K slots of qkv [B, L, 3, H, d]:
  * out = x*cos + rotate_half(x)*sin with rotate_half(x) = [-x2, x1]; conj != 0 applies the transposed rotation

@@ -36,8 +36,8 @@ SIGNATURES = {
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
     "sedd_gate_residual_fwd": "ppipilpflfpllip",
-    "sedd_gate_residual_bwd": "ppipilpflfppllip",
-    "sedd_gate_residual_bwd_reduce": "ppl" + "llip",
+    "sedd_gate_residual_bwd": "ppipilpflfppillip",
+    "sedd_gate_residual_bwd_reduce": "pplp" + "llip",
     "sedd_rotary_qkv": "pippiiiiip",
     "sedd_gelu_fwd": "ppilp",
     "sedd_gelu_bwd": "pppilp",

@@ -29,6 +29,12 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
     *reinterpret_cast<uint2*>(p) = c.u;
 }
 __device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+// v as it reads back after a store in type T
+template <typename T> __device__ __forceinline__ float4 round4(float4 v) {
+    if constexpr (sizeof(T) == 2)
+        return make_float4((float)(bf16_t)v.x, (float)(bf16_t)v.y, (float)(bf16_t)v.z, (float)(bf16_t)v.w);
+    else return v;
+}
 
 #define DISPATCH_DT(code, TT, ...)                              \
     do {                                                        \
@@ -272,10 +278,11 @@ extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x
     return SEDD_OK;
 }
 
-// out_k[b, j] = sum over the chunks of batch b of plane k;  plane 0 additionally summed over b into dw (atomic +=)
+// out_k[b, j] = sum over the chunks of batch b of plane k;  planes in atomic_mask are instead summed over b as well,
+// into a [D] vector (atomic +=)
 __global__ void __launch_bounds__(TPB) chunk_reduce_kernel(const float* __restrict__ ws, int nplanes,
                                                            float* __restrict__ o0, float* __restrict__ o1,
-                                                           float* __restrict__ o2, int64_t ostride, int atomic0,
+                                                           float* __restrict__ o2, int64_t ostride, int atomic_mask,
                                                            int64_t nchunk, int64_t cpb, int D) {
     const int j = blockIdx.x * TPB + threadIdx.x;
     const int64_t b = blockIdx.y;
@@ -286,7 +293,7 @@ __global__ void __launch_bounds__(TPB) chunk_reduce_kernel(const float* __restri
     float* outs[3] = {o0, o1, o2};
     for (int k = 0; k < nplanes; ++k) {
         if (!outs[k]) continue;
-        if (k == 0 && atomic0) atomicAdd(outs[0] + j, s[0]);
+        if ((atomic_mask >> k) & 1) atomicAdd(outs[k] + j, s[k]);  // [D] vector summed over the batch as well
         else outs[k][b * ostride + j] = s[k];
     }
 }
@@ -377,8 +384,8 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
                                                            const TM* __restrict__ gate, int64_t mod_stride,
                                                            const uint8_t* __restrict__ keep, float inv_keep,
                                                            uint64_t seed, uint32_t thr16,
-                                                           TA* __restrict__ da, float* __restrict__ ws, int64_t L,
-                                                           int D, int CR) {
+                                                           TA* __restrict__ da, float* __restrict__ ws,
+                                                           float* __restrict__ ws2, int64_t L, int D, int CR) {
     __shared__ float red[(TPB / 64) * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cpb = (L + CR - 1) / CR;
@@ -386,7 +393,7 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
     const int nrows = (int)((L - c0) < CR ? (L - c0) : CR);
     for (int cb = 0; cb < D; cb += 256) {  // 256-column slabs
         const int c = cb + lane * 4;
-        float4 acc = f4(0.f);
+        float4 acc = f4(0.f), acc2 = f4(0.f);
         if (c < D) {
             const float4 g = load4<TM>(gate + b * mod_stride + c);
             for (int r = wave; r < nrows; r += TPB / 64) {
@@ -400,9 +407,14 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
                 } else if (thr16) {
                     kk = keep4_hashed(seed, off, thr16, inv_keep);
                 }
-                store4<TA>(da + off, make_float4(d.x * g.x * kk.x, d.y * g.y * kk.y, d.z * g.z * kk.z, d.w * g.w * kk.w));
+                const float4 dav = make_float4(d.x * g.x * kk.x, d.y * g.y * kk.y, d.z * g.z * kk.z, d.w * g.w * kk.w);
+                store4<TA>(da + off, dav);
                 acc.x += d.x * av.x * kk.x; acc.y += d.y * av.y * kk.y;
                 acc.z += d.z * av.z * kk.z; acc.w += d.w * av.w * kk.w;
+                if (ws2) {  // column sums of da as stored (the bias gradient of the Linear that produced a)
+                    const float4 r = round4<TA>(dav);
+                    acc2.x += r.x; acc2.y += r.y; acc2.z += r.z; acc2.w += r.w;
+                }
             }
         }
         store4<float>(red + wave * 256 + lane * 4, acc);
@@ -416,12 +428,25 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
             store4<float>(ws + chunk * D + c, s);
         }
         __syncthreads();
+        if (ws2) {
+            store4<float>(red + wave * 256 + lane * 4, acc2);
+            __syncthreads();
+            if (wave == 0 && c < D) {
+                float4 s = load4<float>(red + lane * 4);
+                for (int wv = 1; wv < TPB / 64; ++wv) {
+                    const float4 p = load4<float>(red + wv * 256 + lane * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                store4<float>(ws2 + chunk * D + c, s);
+            }
+            __syncthreads();
+        }
     }
 }
 
 extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const void* gate, int mod_dtype,
                                       int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed,
-                                      float p_drop, void* da, float* ws, int64_t M, int64_t L, int D,
+                                      float p_drop, void* da, float* ws, int want_colsum, int64_t M, int64_t L, int D,
                                       sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_bwd: bad dtype");
     SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "gate_residual_bwd: p_drop %f", (double)p_drop);
@@ -436,20 +461,21 @@ extern "C" int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dt
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
     DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
         hipLaunchKernelGGL((gate_res_bwd_kernel<TA, TM>), dim3((unsigned)nchunk), dim3(TPB), 0, (hipStream_t)stream,
-                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, (TA*)da, ws, L, D,
+                           dout, (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, (TA*)da, ws,
+                           want_colsum ? ws + nchunk * D : (float*)nullptr, L, D,
                            chunk_rows(M))));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
 
-extern "C" int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, int64_t M, int64_t L,
-                                             int D, sedd_stream_t stream) {
+extern "C" int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, float* dbias,
+                                             int64_t M, int64_t L, int D, sedd_stream_t stream) {
     SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0 && D > 0, "gate_residual_bwd_reduce: bad sizes");
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(ws && dgate, "gate_residual_bwd_reduce: null pointer");
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L), B = M / L;
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((D + TPB - 1) / TPB, (unsigned)B), dim3(TPB), 0, (hipStream_t)stream,
-                       ws, 1, dgate, (float*)nullptr, (float*)nullptr, dmod_stride, 0, nchunk, nchunk / B, D);
+                       ws, dbias ? 2 : 1, dgate, dbias, (float*)nullptr, dmod_stride, dbias ? 2 : 0, nchunk, nchunk / B, D);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

@@ -271,7 +271,11 @@ __device__ __forceinline__ void stage_flush(const unsigned char* reg, TO* __rest
                // operand panels resident (+10-14 % on the K = 768 shapes, same-device A/B)
                 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
                 const u32x4 w_ = {v.u.x, v.u.y, v.u.z, v.u.w};
+#ifdef GEMM_PLAIN_STORES
+                *reinterpret_cast<u32x4*>(p) = w_;
+#else
                 __builtin_nontemporal_store(w_, reinterpret_cast<u32x4*>(p));
+#endif
             }
         } else {
             for (int e = 0; e < SC::EPC && gc + e < N; ++e)

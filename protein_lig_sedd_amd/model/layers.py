@@ -199,9 +199,11 @@ def ddit_block_backward(dx2, st, P, n_heads):
     dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(dx2)  # = dx2 + both LN-branch gradients (dx2 itself is autograd's and stays untouched)
     # ---- MLP branch: x2 = x1 + gate_mlp * dropout(mlp(modulate(LN(x1))))
-    dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
-    du, grads["mlp.2.weight"], grads["mlp.2.bias"], grads["mlp.0.bias"] = mlp_out_bwd(
-        st["g"], st["u"], dy, P["mlp.2.weight"], P["mlp.2.bias"], P["mlp.0.bias"])
+    db2, grads["mlp.2.bias"] = _vec_sink(P["mlp.2.bias"], D)  # column sums of dy ride along in the same pass
+    dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"],
+                               dbias=db2).view(M, D)
+    du, grads["mlp.2.weight"], _, grads["mlp.0.bias"] = mlp_out_bwd(
+        st["g"], st["u"], dy, P["mlp.2.weight"], None, P["mlp.0.bias"])
     dh2, grads["mlp.0.weight"], _ = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], None)
     dw2, grads["norm2.weight"] = _vec_sink(P["norm2.weight"], D)
     ops.ln_modulate_bwd(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],

@@ -306,18 +306,19 @@ def gate_residual_fwd(residual, a, gate, keep=None, inv_keep=1.0):
     return out
 
 
-def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0):
-    """-> da (dtype of a); dgate fp32 [B, D] (strided view) written."""
+def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0, dbias=None):
+    """-> da (dtype of a); dgate fp32 [B, D] (strided view) written; dbias fp32 [D] (optional) += da.sum over rows
+    (the bias gradient of the Linear that produced `a`, folded into the same pass)."""
     B, L, D = dout.shape
     M = B * L
     da = torch.empty_like(a)
     nchunk = lib().sedd_ln_bwd_chunks(M, L)
-    ws = torch.empty(nchunk * D, dtype=torch.float32, device=dout.device)
+    ws = torch.empty((2 if dbias is not None else 1) * nchunk * D, dtype=torch.float32, device=dout.device)
     g, mdt, ms = _mod_args(gate)
     kp, seed, pd = _keep_args(keep)
     check(lib().sedd_gate_residual_bwd(_p(dout), _p(a), _dt(a), _p(g), mdt, ms, kp, float(inv_keep), seed, pd, _p(da),
-                                       _p(ws), M, L, D, _stream()), "sedd_gate_residual_bwd")
-    check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), M, L, D, _stream()),
+                                       _p(ws), 0 if dbias is None else 1, M, L, D, _stream()), "sedd_gate_residual_bwd")
+    check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), _p(dbias), M, L, D, _stream()),
           "sedd_gate_residual_bwd_reduce")
     return da
 

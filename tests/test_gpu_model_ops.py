@@ -217,6 +217,11 @@ def test_gate_residual(dtype):
         da = ops.gate_residual_bwd(dout, a, mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], kp, inv)
         assert rel_err(da, ar.grad) < (1e-6 if dtype == torch.float32 else 5e-3)
         assert rel_err(dmod[:, 2 * D:3 * D], gr.grad) < 1e-4
+        # bias-gradient column sums folded into the same pass: dbias += da.sum(rows), da as stored
+        dmod2, dbias = torch.zeros(B, 6 * D, device=DEV), torch.ones(D, device=DEV)
+        da2 = ops.gate_residual_bwd(dout, a, mod[:, 2 * D:3 * D], dmod2[:, 2 * D:3 * D], kp, inv, dbias=dbias)
+        assert torch.equal(da2, da) and torch.equal(dmod2, dmod)
+        assert rel_err(dbias, 1 + da.float().sum((0, 1))) < 1e-5
 
 
 @pytest.mark.parametrize("d", [32, 64, 96])
