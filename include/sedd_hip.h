@@ -112,6 +112,15 @@ int sedd_ln_modulate_fwd(const float* x, const float* w, const float* bias, cons
  * sedd_ln_modulate_bwd_reduce can fold them into dw[D] (+=), dshift[B, .] and dscale[B, .] (fp32, written with
  * stride dmod_stride). */
 int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L);
+/* sedd_ln_modulate_bwd plus the backward of the gated residual that produced x (sedd_gate_residual_bwd on the finished
+ * dx; transformer.py:185's bias_dropout_add_scale feeding :186's norm2) in one pass: da (dy's dtype) = dx * gate_b *
+ * keep*inv_keep, ws_gate fp32 [nchunk, D] = partial sums of dgate (fold with sedd_gate_residual_bwd_reduce).
+ * a has dy's dtype; gate has mod_dtype and row stride mod_stride; dropout by the (seed, p_drop) hash.  D <= 1024. */
+int sedd_ln_modulate_bwd_gate(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                              int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
+                              const float* dx_add, float* ws, const void* a, const void* gate, float inv_keep,
+                              uint64_t seed, float p_drop, void* da, float* ws_gate, int64_t M, int64_t L, int D,
+                              sedd_stream_t stream);
 int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
                          int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
                          const float* dx_add, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
@@ -137,6 +146,16 @@ int sedd_gate_residual_bwd(const float* dout, const void* a, int a_dtype, const 
                            void* da, float* ws, int want_colsum, int64_t M, int64_t L, int D, sedd_stream_t stream);
 int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int64_t dmod_stride, float* dbias, int64_t M,
                                   int64_t L, int D, sedd_stream_t stream);
+
+/* sedd_gate_residual_fwd followed by the next sub-layer's sedd_ln_modulate_fwd in one pass over the row
+ * (transformer.py:185-186: x = bias_dropout_add_scale(attn_out, None, gate_msa, x_skip, p); modulate(norm2(x), ...)):
+ * x_out fp32 [M, D] = residual + gate_b * dropout(a);  y (dtype of a) = LN(x_out) * w * (1 + scale_b) + shift_b;
+ * mean / rstd fp32 [M] saved for backward.  Dropout by the (seed, p_drop) hash only (p_drop == 0: none).  D <= 1024. */
+int sedd_gate_residual_ln_modulate_fwd(const float* residual, const void* a, int a_dtype, const void* gate,
+                                       const void* shift, const void* scale, int mod_dtype, int64_t mod_stride,
+                                       float inv_keep, uint64_t seed, float p_drop, const float* w, float* x_out,
+                                       void* y, float* mean, float* rstd, int64_t M, int64_t L, int D,
+                                       sedd_stream_t stream);
 
 /* Rotary (model/rotary.py:13-51): in-place NeoX rotation of the Q and K slots of qkv [B, L, 3, H, d]:
  * out = x*cos + rotate_half(x)*sin with rotate_half(x) = [-x2, x1]; conj != 0 applies the transposed rotation

@@ -34,10 +34,12 @@ SIGNATURES = {
     "sedd_embedding_bwd": "pppliip",
     "sedd_ln_modulate_fwd": "pppppilpippllip",
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
+    "sedd_ln_modulate_bwd_gate": "pipppilppppp" + "pp" + "flf" + "pp" + "llip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
     "sedd_gate_residual_fwd": "ppipilpflfpllip",
     "sedd_gate_residual_bwd": "ppipilpflfppillip",
     "sedd_gate_residual_bwd_reduce": "pplp" + "llip",
+    "sedd_gate_residual_ln_modulate_fwd": "ppipppil" + "flf" + "ppppp" + "llip",
     "sedd_rotary_qkv": "pippiiiiip",
     "sedd_gelu_fwd": "ppilp",
     "sedd_gelu_bwd": "pppilp",

@@ -132,6 +132,22 @@ extern "C" int sedd_ln_modulate_fwd(const float* x, const float* w, const float*
     return SEDD_OK;
 }
 
+// Counter-based dropout: the keep decision of element e is a pure function of (seed, e), so forward and backward
+// regenerate the same mask instead of writing / reading a [M, D] byte mask (and no torch RNG kernel runs per block).
+// Two rounds of a 32-bit avalanche hash (lowbias32) per group of 4 consecutive elements give four 16-bit uniforms;
+// keep <=> u16 >= thr16 with thr16 = round(p * 65536).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float4 keep4_hashed(uint64_t seed, int64_t off, uint32_t thr16, float inv_keep) {
+    const uint64_t q = (uint64_t)off >> 2;
+    const uint32_t h0 = mix32(mix32((uint32_t)q ^ (uint32_t)seed) + (uint32_t)(q >> 32) + (uint32_t)(seed >> 32));
+    const uint32_t h1 = mix32(h0 ^ 0x9e3779b9U);
+    return make_float4((h0 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h0 >> 16) >= thr16 ? inv_keep : 0.f,
+                       (h1 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h1 >> 16) >= thr16 ? inv_keep : 0.f);
+}
+
 // =================================================================================== LayerNorm + modulate bwd
 // y = xhat*w*(1+sc)+sh, xhat = (x-mu)*rs.  g = dy*w*(1+sc);  dx = rs*(g - mean(g) - xhat*mean(g*xhat));
 // dw += dy*(1+sc)*xhat ; dsh += dy ; dsc += dy*xhat*w.  One block per chunk of <= 32 rows of one batch element.
@@ -140,22 +156,36 @@ extern "C" int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L) {
     return (M / L) * ((L + chunk_rows(M) - 1) / chunk_rows(M));
 }
 
-template <typename TD, typename TM, int NV>
+// GATE: the finished dx row additionally goes through the backward of the gated residual that FEEDS this LayerNorm
+// (x = residual + gate_b * dropout(a), fused_add_dropout_scale.py:13-48): da = dx * gate_b * keep (dtype of dy) and
+// the per-chunk partials of dgate = sum_l dx * a * keep go to ws_gate — what gate_res_bwd_kernel would compute from a
+// second pass over dx.
+struct GateBwdArgs {
+    const void* a; const void* gate; void* da; float* ws_gate; float inv_keep; uint64_t seed; uint32_t thr16;
+};
+template <typename TD, typename TM, int NV, bool GATE>
 __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, const TM* __restrict__ scale,
                                                          int64_t mod_stride, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* dx,
                                                          const float* dx_add, float* __restrict__ ws, int64_t nchunk,
-                                                         int64_t L, int D, int CR) {
+                                                         int64_t L, int D, int CR, GateBwdArgs ga) {
     __shared__ float red[3 * NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cpb = (L + CR - 1) / CR;
     const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;
     const int nrows = (int)((L - c0) < CR ? (L - c0) : CR);
     float4 ww[NV], sc1[NV], aw[NV], ash[NV], asc[NV];
+    float4 gt[GATE ? NV : 1], agt[GATE ? NV : 1];
+    const TD* ga_a = reinterpret_cast<const TD*>(ga.a);
+    TD* ga_da = reinterpret_cast<TD*>(ga.da);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = k * 256 + lane * 4;
+        if constexpr (GATE) {
+            gt[k] = c < D ? load4<TM>(reinterpret_cast<const TM*>(ga.gate) + b * mod_stride + c) : f4(0.f);
+            agt[k] = f4(0.f);
+        }
         ww[k] = c < D ? load4<float>(w + c) : f4(0.f);
         float4 s = f4(0.f);
         if (scale && c < D) s = load4<TM>(scale + b * mod_stride + c);
@@ -165,9 +195,9 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
     // Rows are software-pipelined: the loads of this wave's next row (dy, x, the residual gradient, mean / rstd) are
     // issued before the current row's two wave reductions, so a wave keeps two rows of HBM traffic in flight.
     // (dx_add may alias dx: a row is read and then written by the same wave, and rows are disjoint between waves.)
-    float4 dA[NV], xA[NV], pA[NV];
+    float4 dA[NV], xA[NV], pA[NV], gA[GATE ? NV : 1];
     float muA = 0.f, rsA = 0.f;
-#define LN_BWD_LOAD(r_, d_, x_, p_, mu_, rs_)                                                        \
+#define LN_BWD_LOAD(r_, d_, x_, p_, mu_, rs_, g_)                                                    \
     do {                                                                                             \
         const int64_t row_ = b * L + c0 + (r_);                                                      \
         mu_ = mean[row_]; rs_ = rstd[row_];                                                          \
@@ -178,15 +208,16 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                 d_[k] = load4<TD>(dy + row_ * D + c);                                                \
                 x_[k] = load4<float>(x + row_ * D + c);                                              \
                 if (dx_add) p_[k] = load4<float>(dx_add + row_ * D + c);                             \
+                if constexpr (GATE) g_[k] = load4<TD>(ga_a + row_ * D + c);                          \
             }                                                                                        \
         }                                                                                            \
     } while (0)
-    if (wave < nrows) LN_BWD_LOAD(wave, dA, xA, pA, muA, rsA);
+    if (wave < nrows) LN_BWD_LOAD(wave, dA, xA, pA, muA, rsA, gA);
     for (int r = wave; r < nrows; r += TPB / 64) {
         const int64_t row = b * L + c0 + r;
-        float4 dB[NV], xB[NV], pB[NV];
+        float4 dB[NV], xB[NV], pB[NV], gB[GATE ? NV : 1];
         float muB = 0.f, rsB = 0.f;
-        if (r + TPB / 64 < nrows) LN_BWD_LOAD(r + TPB / 64, dB, xB, pB, muB, rsB);
+        if (r + TPB / 64 < nrows) LN_BWD_LOAD(r + TPB / 64, dB, xB, pB, muB, rsB, gB);
         const float mu = muA, rs = rsA;
         float4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -213,10 +244,22 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                                        rs * (g[k].z - c1 - xh[k].z * c2), rs * (g[k].w - c1 - xh[k].w * c2));
                 if (dx_add) { o.x += pA[k].x; o.y += pA[k].y; o.z += pA[k].z; o.w += pA[k].w; }
                 store4<float>(dx + row * D + c, o);
+                if constexpr (GATE) {
+                    float4 kk = f4(1.f);
+                    if (ga.thr16) kk = keep4_hashed(ga.seed, row * D + c, ga.thr16, ga.inv_keep);
+                    store4<TD>(ga_da + row * D + c, make_float4(o.x * gt[k].x * kk.x, o.y * gt[k].y * kk.y,
+                                                                 o.z * gt[k].z * kk.z, o.w * gt[k].w * kk.w));
+                    agt[k].x += o.x * gA[k].x * kk.x; agt[k].y += o.y * gA[k].y * kk.y;
+                    agt[k].z += o.z * gA[k].z * kk.z; agt[k].w += o.w * gA[k].w * kk.w;
+                }
             }
         }
 #pragma unroll
         for (int k = 0; k < NV; ++k) { dA[k] = dB[k]; xA[k] = xB[k]; pA[k] = pB[k]; }
+        if constexpr (GATE) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) gA[k] = gB[k];
+        }
         muA = muB; rsA = rsB;
     }
 #undef LN_BWD_LOAD
@@ -247,35 +290,81 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
         const int c = rem * 4;
         if (c < D) store4<float>(ws + ((int64_t)plane * nchunk + chunk) * D + c, load4<float>(red + plane * NV * 256 + c));
     }
+    if constexpr (GATE) {  // the gate-gradient partials take the same wave-by-wave fold through plane 0 of `red`
+        __syncthreads();
+        for (int wv = 0; wv < TPB / 64; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    float* r0 = red + k * 256 + lane * 4;
+                    if (wv == 0) store4<float>(r0, agt[k]);
+                    else {
+                        const float4 p = load4<float>(r0);
+                        store4<float>(r0, make_float4(p.x + agt[k].x, p.y + agt[k].y, p.z + agt[k].z, p.w + agt[k].w));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < NV * 64; i += TPB) {
+            const int c = i * 4;
+            if (c < D) store4<float>(ga.ws_gate + chunk * D + c, load4<float>(red + c));
+        }
+    }
+}
+
+static int ln_modulate_bwd_impl(const char* nm, const void* dy, int dy_dtype, const float* x, const float* w,
+                                const void* scale, int mod_dtype, int64_t mod_stride, const float* mean,
+                                const float* rstd, float* dx, const float* dx_add, float* ws, int64_t M, int64_t L, int D,
+                                const GateBwdArgs* ga, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dy_dtype) && dt_ok(mod_dtype), "%s: bad dtype", nm);
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "%s: bad sizes M=%ld L=%ld", nm, (long)M, (long)L);
+    if (D <= 0 || D % 4 != 0 || D > (ga ? 1024 : 2048) || mod_stride % 4 != 0) {
+        sedd_set_error("%s: D=%d unsupported (need D %% 4 == 0, D <= %d)", nm, D, ga ? 1024 : 2048);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(dy && x && w && mean && rstd && dx && ws, "%s: null pointer", nm);
+    SEDD_CHECK_ARG(!ga || (ga->a && ga->gate && ga->da && ga->ws_gate), "%s: null pointer", nm);
+    const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
+    hipStream_t st = (hipStream_t)stream;
+    const GateBwdArgs g0 = ga ? *ga : GateBwdArgs{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0};
+#define LN_BWD_LAUNCH(NV_, G_)                                                                                        \
+    hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, NV_, G_>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy, x, \
+                       w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M), g0)
+    DISPATCH_DT(dy_dtype, TD, DISPATCH_DT(mod_dtype, TM, {
+        if (ga) {
+            if (D <= 768) LN_BWD_LAUNCH(3, true);
+            else LN_BWD_LAUNCH(4, true);
+        } else if (D <= 768) LN_BWD_LAUNCH(3, false);
+        else if (D <= 1024) LN_BWD_LAUNCH(4, false);
+        else LN_BWD_LAUNCH(8, false);
+    }));
+#undef LN_BWD_LAUNCH
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
 }
 
 extern "C" int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
                                     int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd,
                                     float* dx, const float* dx_add, float* ws, int64_t M, int64_t L, int D,
                                     sedd_stream_t stream) {
-    SEDD_CHECK_ARG(dt_ok(dy_dtype) && dt_ok(mod_dtype), "ln_modulate_bwd: bad dtype");
-    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "ln_modulate_bwd: bad sizes M=%ld L=%ld", (long)M, (long)L);
-    if (D <= 0 || D % 4 != 0 || D > 2048 || mod_stride % 4 != 0) {
-        sedd_set_error("ln_modulate_bwd: D=%d unsupported (need D %% 4 == 0, D <= 2048)", D);
-        return SEDD_ERR_UNSUPPORTED_SHAPE;
-    }
-    if (M == 0) return SEDD_OK;
-    SEDD_CHECK_ARG(dy && x && w && mean && rstd && dx && ws, "ln_modulate_bwd: null pointer");
-    const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
-    hipStream_t st = (hipStream_t)stream;
-    DISPATCH_DT(dy_dtype, TD, DISPATCH_DT(mod_dtype, TM, {
-        if (D <= 768)
-            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 3>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
-        else if (D <= 1024)
-            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 4>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
-        else
-            hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, 8>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy,
-                               x, w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M));
-    }));
-    SEDD_LAUNCH_CHECK();
-    return SEDD_OK;
+    return ln_modulate_bwd_impl("ln_modulate_bwd", dy, dy_dtype, x, w, scale, mod_dtype, mod_stride, mean, rstd, dx,
+                                dx_add, ws, M, L, D, nullptr, stream);
+}
+
+// sedd_ln_modulate_bwd + the sedd_gate_residual_bwd of the gated residual that produced x, in one pass over the rows:
+// da (dy's dtype) = dx * gate_b * keep, ws_gate fp32 [nchunk, D] = partials of dgate (fold with
+// sedd_gate_residual_bwd_reduce).  a in dy's dtype; gate in mod_dtype with row stride mod_stride.
+extern "C" int sedd_ln_modulate_bwd_gate(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                                         int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd,
+                                         float* dx, const float* dx_add, float* ws, const void* a, const void* gate,
+                                         float inv_keep, uint64_t seed, float p_drop, void* da, float* ws_gate,
+                                         int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_modulate_bwd_gate: p_drop %f", (double)p_drop);
+    const GateBwdArgs ga{a, gate, da, ws_gate, inv_keep, seed, (uint32_t)(p_drop * 65536.0f + 0.5f)};
+    return ln_modulate_bwd_impl("ln_modulate_bwd_gate", dy, dy_dtype, x, w, scale, mod_dtype, mod_stride, mean, rstd, dx,
+                                dx_add, ws, M, L, D, &ga, stream);
 }
 
 // out_k[b, j] = sum over the chunks of batch b of plane k;  planes in atomic_mask are instead summed over b as well,
@@ -311,22 +400,6 @@ extern "C" int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* ds
 }
 
 // ====================================================================================== gated residual fwd
-// Counter-based dropout: the keep decision of element e is a pure function of (seed, e), so forward and backward
-// regenerate the same mask instead of writing / reading a [M, D] byte mask (and no torch RNG kernel runs per block).
-// Two rounds of a 32-bit avalanche hash (lowbias32) per group of 4 consecutive elements give four 16-bit uniforms;
-// keep <=> u16 >= thr16 with thr16 = round(p * 65536).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ float4 keep4_hashed(uint64_t seed, int64_t off, uint32_t thr16, float inv_keep) {
-    const uint64_t q = (uint64_t)off >> 2;
-    const uint32_t h0 = mix32(mix32((uint32_t)q ^ (uint32_t)seed) + (uint32_t)(q >> 32) + (uint32_t)(seed >> 32));
-    const uint32_t h1 = mix32(h0 ^ 0x9e3779b9U);
-    return make_float4((h0 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h0 >> 16) >= thr16 ? inv_keep : 0.f,
-                       (h1 & 0xffffU) >= thr16 ? inv_keep : 0.f, (h1 >> 16) >= thr16 ? inv_keep : 0.f);
-}
-
 // fused_add_dropout_scale.py:13-48 with bias == None: out = residual + gate_b * dropout(a)
 template <typename TA, typename TM>
 __global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restrict__ res, const TA* __restrict__ a,
@@ -373,6 +446,104 @@ extern "C" int sedd_gate_residual_fwd(const float* residual, const void* a, int 
     DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM,
         hipLaunchKernelGGL((gate_res_fwd_kernel<TA, TM>), grid, dim3(TPB), 0, (hipStream_t)stream, residual,
                            (const TA*)a, (const TM*)gate, mod_stride, keep, inv_keep, seed, thr16, out, M, L, D)));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+// ============================================================== gated residual + LayerNorm-modulate, one pass
+// x1 = residual + gate_b * dropout(a) (fused_add_dropout_scale.py:13-48) followed by the next sub-layer's
+// h = LN(x1) * w * (1 + scale_b) + shift_b (transformer.py:30-38, :186): the row of x1 never leaves the registers
+// between the two, so x1 is written once and not read back (one wave per row, like ln_mod_fwd_kernel).
+template <typename TA, typename TM, int NV>
+__global__ void __launch_bounds__(TPB) gate_res_ln_mod_fwd_kernel(
+    const float* __restrict__ res, const TA* __restrict__ a, const TM* __restrict__ gate, const TM* __restrict__ shift,
+    const TM* __restrict__ scale, int64_t mod_stride, float inv_keep, uint64_t seed, uint32_t thr16,
+    const float* __restrict__ w, float* __restrict__ x1, TA* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t M, int64_t L, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t b = row / L;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        v[k] = f4(0.f);
+        if (c < D) {
+            const int64_t off = row * D + c;
+            float4 av = load4<TA>(a + off);
+            if (thr16) {
+                const float4 kk = keep4_hashed(seed, off, thr16, inv_keep);
+                av.x *= kk.x; av.y *= kk.y; av.z *= kk.z; av.w *= kk.w;
+            }
+            const float4 g = load4<TM>(gate + b * mod_stride + c);
+            const float4 r = load4<float>(res + off);
+            v[k] = make_float4(r.x + g.x * av.x, r.y + g.y * av.y, r.z + g.z * av.z, r.w + g.w * av.w);
+            store4<float>(x1 + off, v[k]);
+        }
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < D) {
+            const float a0 = v[k].x - mu, a1 = v[k].y - mu, a2 = v[k].z - mu, a3 = v[k].w - mu;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < D) {
+            const float4 ww = load4<float>(w + c);
+            const float4 sc = load4<TM>(scale + b * mod_stride + c);
+            const float4 sh = load4<TM>(shift + b * mod_stride + c);
+            float4 o;
+            o.x = (v[k].x - mu) * rs * ww.x; o.y = (v[k].y - mu) * rs * ww.y;
+            o.z = (v[k].z - mu) * rs * ww.z; o.w = (v[k].w - mu) * rs * ww.w;
+            o.x = o.x * (1.0f + sc.x) + sh.x; o.y = o.y * (1.0f + sc.y) + sh.y;
+            o.z = o.z * (1.0f + sc.z) + sh.z; o.w = o.w * (1.0f + sc.w) + sh.w;
+            store4<TA>(y + row * D + c, o);
+        }
+    }
+}
+
+extern "C" int sedd_gate_residual_ln_modulate_fwd(const float* residual, const void* a, int a_dtype, const void* gate,
+                                                  const void* shift, const void* scale, int mod_dtype,
+                                                  int64_t mod_stride, float inv_keep, uint64_t seed, float p_drop,
+                                                  const float* w, float* x_out, void* y, float* mean, float* rstd,
+                                                  int64_t M, int64_t L, int D, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(a_dtype) && dt_ok(mod_dtype), "gate_residual_ln_modulate_fwd: bad dtype");
+    SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "gate_residual_ln_modulate_fwd: p_drop %f", (double)p_drop);
+    const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0, "gate_residual_ln_modulate_fwd: bad sizes");
+    if (D <= 0 || D % 4 != 0 || D > 1024 || mod_stride % 4 != 0) {
+        sedd_set_error("gate_residual_ln_modulate_fwd: D=%d unsupported (need D %% 4 == 0, D <= 1024)", D);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    if (M == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(residual && a && gate && shift && scale && w && x_out && y && mean && rstd,
+                   "gate_residual_ln_modulate_fwd: null pointer");
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_DT(a_dtype, TA, DISPATCH_DT(mod_dtype, TM, {
+        if (D <= 768)
+            hipLaunchKernelGGL((gate_res_ln_mod_fwd_kernel<TA, TM, 3>), grid, dim3(TPB), 0, st, residual, (const TA*)a,
+                               (const TM*)gate, (const TM*)shift, (const TM*)scale, mod_stride, inv_keep, seed, thr16, w,
+                               x_out, (TA*)y, mean, rstd, M, L, D);
+        else
+            hipLaunchKernelGGL((gate_res_ln_mod_fwd_kernel<TA, TM, 4>), grid, dim3(TPB), 0, st, residual, (const TA*)a,
+                               (const TM*)gate, (const TM*)shift, (const TM*)scale, mod_stride, inv_keep, seed, thr16, w,
+                               x_out, (TA*)y, mean, rstd, M, L, D);
+    }));
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

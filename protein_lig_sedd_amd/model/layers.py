@@ -173,8 +173,12 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
     a = linear_fwd(o.view(M, D), P["attn_out.weight"]).view(B, L, D)
     inv = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     keep1 = dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
-    x1 = ops.gate_residual_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv)
-    h2, mean2, rstd2 = ops.ln_modulate_fwd(x1, w2, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=cdt)
+    if ops.gate_residual_ln_modulate_supported(x, a, keep1):  # x1 and LN(x1) in one pass over the rows
+        x1, h2, mean2, rstd2 = ops.gate_residual_ln_modulate_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv, w2,
+                                                                 mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D])
+    else:
+        x1 = ops.gate_residual_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv)
+        h2, mean2, rstd2 = ops.ln_modulate_fwd(x1, w2, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=cdt)
     if save:
         g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True, want_pre=True)
     else:
@@ -206,10 +210,16 @@ def ddit_block_backward(dx2, st, P, n_heads):
         st["g"], st["u"], dy, P["mlp.2.weight"], None, P["mlp.0.bias"])
     dh2, grads["mlp.0.weight"], _ = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], None)
     dw2, grads["norm2.weight"] = _vec_sink(P["norm2.weight"], D)
-    ops.ln_modulate_bwd(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],
-                        st["rstd2"], dx, dx2, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
     # ---- attention branch: x1 = x + gate_msa * dropout(attn_out(attn(rotary(qkv(modulate(LN(x)))))))
-    da = ops.gate_residual_bwd(dx, st["a"], mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], st["keep1"], st["inv"]).view(M, D)
+    if ops.gate_residual_ln_modulate_supported(st["x1"], st["a"], st["keep1"]) and dh2.dtype == st["a"].dtype:
+        # norm2's backward and the gated residual's backward share one pass over the rows of dx
+        da = ops.ln_modulate_bwd_gate(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D],
+                                      st["mean2"], st["rstd2"], dx, dx2, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D],
+                                      st["a"], mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], st["keep1"], st["inv"]).view(M, D)
+    else:
+        ops.ln_modulate_bwd(dh2.view(B, L, D), st["x1"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],
+                            st["rstd2"], dx, dx2, dw2, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
+        da = ops.gate_residual_bwd(dx, st["a"], mod[:, 2 * D:3 * D], dmod[:, 2 * D:3 * D], st["keep1"], st["inv"]).view(M, D)
     do, grads["attn_out.weight"], _ = linear_bwd(st["o"].view(M, D), da, P["attn_out.weight"])
     qkv = st["qkv"]
     dqkv = torch.empty_like(qkv)

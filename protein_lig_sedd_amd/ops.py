@@ -276,6 +276,36 @@ def ln_modulate_bwd(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dsc
           "sedd_ln_modulate_bwd_reduce")
 
 
+def ln_modulate_bwd_gate(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dscale, a, gate, dgate, keep, inv_keep):
+    """ln_modulate_bwd + gate_residual_bwd(dx, a, gate, dgate, keep, inv_keep) in one pass over the rows -> da.
+    (x = residual + gate * dropout(a) is the gated residual that feeds this LayerNorm; keep: DropSeed or None.)"""
+    add = dx if accumulate is True else (None if (accumulate is False or accumulate is None) else accumulate)
+    if add is not None and (add.shape != dx.shape or add.dtype != torch.float32 or not add.is_contiguous()):
+        raise ValueError("ln_modulate_bwd_gate: addend must be a contiguous fp32 tensor of dx's shape")
+    if a.dtype != dy.dtype or a.shape != dy.shape or not a.is_contiguous():
+        raise ValueError("ln_modulate_bwd_gate: a must match dy in dtype and shape")
+    B, L, D = x.shape
+    M = B * L
+    nchunk = lib().sedd_ln_bwd_chunks(M, L)
+    ws = torch.empty(4 * nchunk * D, dtype=torch.float32, device=x.device)
+    wsg = ws[3 * nchunk * D:]
+    sc, mdt, ms = _mod_args(scale)
+    g, gdt, gs = _mod_args(gate)
+    if (gdt, gs) != (mdt, ms):
+        raise ValueError("scale and gate must be slices of one modulation tensor")
+    _, seed, pd = _keep_args(keep)
+    da = torch.empty_like(a)
+    check(lib().sedd_ln_modulate_bwd_gate(_p(dy), _dt(dy), _p(x), _p(w), _p(sc), mdt, ms, _p(mean), _p(rstd), _p(dx),
+                                          _p(add), _p(ws), _p(a), _p(g), float(inv_keep), seed, pd, _p(da), _p(wsg), M, L,
+                                          D, _stream()), "sedd_ln_modulate_bwd_gate")
+    dstride = dshift.stride(0) if dshift is not None else (dscale.stride(0) if dscale is not None else D)
+    check(lib().sedd_ln_modulate_bwd_reduce(_p(ws), _p(dw), _p(dshift), _p(dscale), dstride, M, L, D, _stream()),
+          "sedd_ln_modulate_bwd_reduce")
+    check(lib().sedd_gate_residual_bwd_reduce(_p(wsg), _p(dgate), dgate.stride(0), None, M, L, D, _stream()),
+          "sedd_gate_residual_bwd_reduce")
+    return da
+
+
 class DropSeed:
     """Dropout by counter-based hash: (seed, p) stand in for a [M, D] keep-mask; forward and backward regenerate the
     same mask in the kernel (sedd_gate_residual_fwd / _bwd)."""
@@ -304,6 +334,33 @@ def gate_residual_fwd(residual, a, gate, keep=None, inv_keep=1.0):
     check(lib().sedd_gate_residual_fwd(_p(residual), _p(a), _dt(a), _p(g), mdt, ms, kp, float(inv_keep), seed, pd,
                                        _p(out), B * L, L, D, _stream()), "sedd_gate_residual_fwd")
     return out
+
+
+def gate_residual_ln_modulate_supported(residual, a, keep):
+    return (residual.shape[-1] <= 1024 and (keep is None or isinstance(keep, DropSeed))
+            and not os.environ.get("SEDD_NO_FUSED_GATE_LN"))
+
+
+def gate_residual_ln_modulate_fwd(residual, a, gate, keep, inv_keep, w, shift, scale):
+    """x1 = residual + gate * dropout(a); h = LN(x1) * w * (1 + scale) + shift in one pass over the rows.
+    gate / shift / scale: [B, D] slices of one modulation tensor; keep: DropSeed or None.
+    -> (x1 fp32, h in a's dtype, mean [M], rstd [M])."""
+    B, L, D = residual.shape
+    M = B * L
+    g, mdt, ms = _mod_args(gate)
+    sh, mdt2, ms2 = _mod_args(shift)
+    sc, mdt3, ms3 = _mod_args(scale)
+    if not (mdt == mdt2 == mdt3 and ms == ms2 == ms3):
+        raise ValueError("gate / shift / scale must be slices of one modulation tensor")
+    _, seed, pd = _keep_args(keep)
+    x1 = torch.empty_like(residual)
+    h = torch.empty(B, L, D, dtype=a.dtype, device=a.device)
+    mean = torch.empty(M, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=a.device)
+    check(lib().sedd_gate_residual_ln_modulate_fwd(_p(residual), _p(a), _dt(a), _p(g), _p(sh), _p(sc), mdt, ms,
+                                                   float(inv_keep), seed, pd, _p(w), _p(x1), _p(h), _p(mean), _p(rstd),
+                                                   M, L, D, _stream()), "sedd_gate_residual_ln_modulate_fwd")
+    return x1, h, mean, rstd
 
 
 def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0, dbias=None):

@@ -224,6 +224,54 @@ def test_gate_residual(dtype):
         assert rel_err(dbias, 1 + da.float().sum((0, 1))) < 1e-5
 
 
+@pytest.mark.parametrize("B,L,D", [(3, 40, 768), (2, 33, 1024), (2, 5, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gate_residual_ln_modulate_fused_matches_the_two_kernels(B, L, D, dtype, p):
+    ops = _ops()
+    torch.manual_seed(D + L)
+    res = torch.randn(B, L, D, device=DEV)
+    a = torch.randn(B, L, D, device=DEV).to(dtype)
+    w = 1 + 0.1 * torch.randn(D, device=DEV)
+    mod = (0.3 * torch.randn(B, 6 * D, device=DEV)).to(dtype)
+    keep = ops.DropSeed(p, seed=1234) if p > 0 else None
+    inv = 1.0 / (1.0 - p)
+    assert ops.gate_residual_ln_modulate_supported(res, a, keep)
+    x1, h, mean, rstd = ops.gate_residual_ln_modulate_fwd(res, a, mod[:, 2 * D:3 * D], keep, inv, w, mod[:, 3 * D:4 * D],
+                                                           mod[:, 4 * D:5 * D])
+    x1r = ops.gate_residual_fwd(res, a, mod[:, 2 * D:3 * D], keep, inv)
+    hr, meanr, rstdr = ops.ln_modulate_fwd(x1r, w, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=dtype)
+    assert torch.equal(x1, x1r)
+    assert torch.equal(mean, meanr) and torch.equal(rstd, rstdr) and torch.equal(h, hr)
+
+
+@pytest.mark.parametrize("B,L,D", [(3, 40, 768), (2, 70, 1024), (2, 5, 64), (40, 512, 768)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_ln_modulate_bwd_gate_fused_matches_the_two_kernels(B, L, D, dtype, p):
+    ops = _ops()
+    torch.manual_seed(D + L + 1)
+    x = torch.randn(B, L, D, device=DEV) * 2 + 0.5
+    dy = torch.randn(B, L, D, device=DEV).to(dtype)
+    a = torch.randn(B, L, D, device=DEV).to(dtype)
+    add = torch.randn(B, L, D, device=DEV)
+    w = 1 + 0.1 * torch.randn(D, device=DEV)
+    mod = (0.3 * torch.randn(B, 6 * D, device=DEV)).to(dtype)
+    keep = ops.DropSeed(p, seed=77) if p > 0 else None
+    inv = 1.0 / (1.0 - p)
+    _, mean, rstd = ops.ln_modulate_fwd(x, w, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=dtype)
+    dx1, dw1, dm1 = torch.empty_like(x), torch.zeros(D, device=DEV), torch.zeros(B, 6 * D, device=DEV)
+    ops.ln_modulate_bwd(dy, x, w, mod[:, 4 * D:5 * D], mean, rstd, dx1, add, dw1, dm1[:, 3 * D:4 * D], dm1[:, 4 * D:5 * D])
+    da1 = ops.gate_residual_bwd(dx1, a, mod[:, 2 * D:3 * D], dm1[:, 2 * D:3 * D], keep, inv)
+    dx2, dw2, dm2 = torch.empty_like(x), torch.zeros(D, device=DEV), torch.zeros(B, 6 * D, device=DEV)
+    da2 = ops.ln_modulate_bwd_gate(dy, x, w, mod[:, 4 * D:5 * D], mean, rstd, dx2, add, dw2, dm2[:, 3 * D:4 * D],
+                                   dm2[:, 4 * D:5 * D], a, mod[:, 2 * D:3 * D], dm2[:, 2 * D:3 * D], keep, inv)
+    assert torch.equal(dx2, dx1) and torch.equal(da2, da1)
+    assert torch.equal(dm2[:, 3 * D:5 * D], dm1[:, 3 * D:5 * D])
+    assert rel_err(dw2, dw1) < 1e-5                                   # (atomic adds over the batch: order varies)
+    assert rel_err(dm2[:, 2 * D:3 * D], dm1[:, 2 * D:3 * D]) < 1e-5   # (rows fold in another order than gate_res_bwd's)
+
+
 @pytest.mark.parametrize("d", [32, 64, 96])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_rotary(d, dtype):
