@@ -250,6 +250,14 @@ __device__ __forceinline__ void store_row_rot(T* row, const f32x4 (&acc)[D / 16]
     }
 }
 
+// 1-D launch, XCD-aware: the blocks that share a (batch, head) — and so re-read the same K/V (or Q/dO) tiles — get
+// consecutive slots of ONE XCD instead of being dealt round-robin over the eight L2s (PMC: the 4 query blocks of a
+// head each pulled K/V through a different L2, 450-620 MB of fabric reads per launch against 150-250 MB of operands).
+__device__ __forceinline__ int attn_xcd_remap(int bid, int nwg) {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 struct AttnShape {
     int H, Lq, Lk;
     int64_t q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls;
@@ -269,7 +277,9 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
     __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const int nob = (sh.Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lin % nob, by = lin / nob;
+    const int b = by / sh.H, h = by % sh.H;
     const T* qb = q + b * sh.q_bs + (int64_t)h * D;
     const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
     const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
@@ -280,7 +290,7 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     int qrow[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        qrow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        qrow[mt] = bx * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
         qf[mt] = qrow[mt] < sh.Lq ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
     }
     float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
@@ -380,7 +390,9 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     __shared__ __attribute__((aligned(16))) T Ks[TILE * LS];
     __shared__ __attribute__((aligned(16))) T Vs[TILE * LS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const int nob = (sh.Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lin % nob, by = lin / nob;
+    const int b = by / sh.H, h = by % sh.H;
     const T* qb = q + b * sh.q_bs + (int64_t)h * D;
     const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
     const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
@@ -393,7 +405,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     float lq[2], dl[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        qrow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        qrow[mt] = bx * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
         const bool ok = qrow[mt] < sh.Lq;
         qf[mt] = ok ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
         dof[mt] = ok ? load_rowfrag<T, D>(dob + (int64_t)qrow[mt] * sh.o_ls, g) : zero_rowfrag<T, D>();
@@ -487,7 +499,9 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
     __shared__ __attribute__((aligned(16))) T dOs[TILE * LS];
     __shared__ __attribute__((aligned(16))) float lse_s[TILE], del_s[TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
-    const int b = blockIdx.y / sh.H, h = blockIdx.y % sh.H;
+    const int nob = (sh.Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = lin % nob, by = lin / nob;
+    const int b = by / sh.H, h = by % sh.H;
     const T* qb = q + b * sh.q_bs + (int64_t)h * D;
     const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
     const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
@@ -499,7 +513,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
     bool kvalid[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        krow[mt] = blockIdx.x * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
+        krow[mt] = bx * OWN_PER_BLOCK + wave * OWN_PER_WAVE + mt * 16 + i;
         const bool ok = krow[mt] < sh.Lk;
         kf[mt] = ok ? load_rowfrag<T, D>(kb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
         vf[mt] = ok ? load_rowfrag<T, D>(vb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
@@ -590,7 +604,7 @@ static int check_attn(const char* nm, int dtype, int B, int H, int Lq, int Lk, i
         sedd_set_error("%s: head dim %d / strides unsupported (d in {32,64,96,128}, strides multiples of %d)", nm, d, al);
         return SEDD_ERR_UNSUPPORTED_SHAPE;
     }
-    SEDD_CHECK_ARG((int64_t)B * H < 65536, "%s: B*H = %ld exceeds the grid limit 65535", nm, (long)B * H);
+    SEDD_CHECK_ARG((int64_t)B * H * ((Lq > Lk ? Lq : Lk) / OWN_PER_BLOCK + 1) < (1LL << 31), "%s: too many blocks", nm);
     return SEDD_OK;
 }
 
@@ -620,7 +634,7 @@ extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr};
-    const dim3 grid((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
+    const dim3 grid((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
     const bool plain = !key_mask && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
 #define FWD_LAUNCH(PL) hipLaunchKernelGGL((attn_fwd_kernel<T, D, PL>), grid, dim3(256), 0, (hipStream_t)stream,       \
                                           (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, key_mask, sh)
@@ -648,7 +662,8 @@ extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const 
     SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin};
     hipStream_t st = (hipStream_t)stream;
-    const dim3 gq((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H), gk((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, B * H);
+    const dim3 gq((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H)),
+        gk((unsigned)((int64_t)((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
     const bool plain_q = !key_mask && Lk % TILE == 0, plain_k = !key_mask && Lk % OWN_PER_BLOCK == 0;
 #define DQ_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, PL>), gq, dim3(256), 0, st, (const T*)q,           \
                                          (const T*)k, (const T*)v, (const T*)o, (const T*)dout, lse, delta, key_mask,  \
