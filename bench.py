@@ -91,8 +91,8 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 # average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
-# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r1b_pmc_hbm_traffic.csv
-GEMM_HBM_BYTES_PER_LAUNCH = 286.9e6
+# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r1f_pmc_hbm_traffic.csv
+GEMM_HBM_BYTES_PER_LAUNCH = 290.6e6
 
 
 def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
@@ -225,7 +225,7 @@ def main():
                                    "Linear fwd / dgrad / wgrad launch of the step",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": GEMM_HBM_BYTES_PER_LAUNCH if (B, L) == (64, 512) else None,
-                         "traffic_source": "profiles/r1b_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
+                         "traffic_source": "profiles/r1f_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
                                            "rocprofv3 --pmc passes of this command, average over the bf16 GEMM launches)",
                          "launches_per_step": n_g / max(args.steps, 1),
                          "avg_launch_us": 1e3 * ms_g / max(n_g, 1),
