@@ -98,7 +98,14 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
             dyp = torch.zeros(dy2d.shape[0], Wt.shape[1], dtype=dy2d.dtype, device=dy2d.device)
             dyp[:, :dy2d.shape[1]].copy_(dy2d)
             dy2d = dyp
-        dx = ops.gemm_nt(dy2d, Wt, out_dtype=dx_dtype)
+        if (dx_dtype == torch.float32 and dy2d.dtype == torch.bfloat16 and dy2d.shape[0] <= 128 and Wt.shape[1] >= 1024
+                and not os.environ.get("SEDD_NO_SMALL_SPLITK")):
+            # few rows, long reduction (adaLN: dc [B, C] = dmod [B, 6D] W): one output tile, so let the kernel split K
+            # over blocks — which it does for accumulating fp32 outputs — instead of one block walking all of K
+            dx = torch.zeros(dy2d.shape[0], Wt.shape[0], dtype=torch.float32, device=dy2d.device)
+            ops.gemm_nt(dy2d, Wt, out=dx, accumulate=True)
+        else:
+            dx = ops.gemm_nt(dy2d, Wt, out_dtype=dx_dtype)
     return dx, dW, db
 
 
