@@ -136,6 +136,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=8, help="Analytic sampler steps timed for the seqs/s side metric")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints a version banner at communicator
+    # creation) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the run and the JSON goes to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("SEDD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SEDD_BENCH_WATCHDOG"]), exit=True)
@@ -236,7 +242,8 @@ def main():
             out["sampling"] = samp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
