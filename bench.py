@@ -42,7 +42,7 @@ def randomize(model, seed):
                 p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=12.0):
     """The CPU oracle (oracle/sedd_cpu.py, kind "port": a plain-PyTorch fp32 restatement of the reference's train step)
     timed on this host's cores on a bounded sample of the same workload: same model, L=512, batch 2."""
     from oracle import sedd_cpu as O
@@ -82,7 +82,7 @@ def cpu_baseline(seconds_budget=25.0):
 
     step(1)  # warm-up
     t0, n = time.perf_counter(), 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 32):
         step(n + 2)
         n += 1
     dt = time.perf_counter() - t0
