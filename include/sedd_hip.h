@@ -203,6 +203,14 @@ int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
 int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                        int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
+/* The QKV projection with the rotary position embedding applied in the GEMM epilogue (transformer.py:165-171: attn_qkv,
+ * rearrange 'b s (three h d) -> b s three h d', rotary.apply_rotary_pos_emb): C = packed qkv [M, 3*H*d] = A[M,K] *
+ * B[N,K]^T (+ bias), then the NeoX rotation of sedd_rotary_qkv (conj = 0) on the q and k columns with position
+ * row % L; cos / sin fp32 [L, d/2].  bf16 in/out, d == 64, N == 3*H*d, K % 32 == 0, M >= 192, M % L == 0, 16-byte
+ * aligned C rows; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then use sedd_gemm_nt + sedd_rotary_qkv). */
+int sedd_gemm_nt_rotary(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                        int out_dtype, const float* bias, int epilogue, const float* cos, const float* sin, int L, int H,
+                        int d, int64_t M, int64_t N, int64_t K, sedd_stream_t stream);
 /* Data gradient of nn.Linear against the weight AS STORED (dX = dY W with W [out_features, in_features] row-major; the
  * reference gets it from torch.nn.functional.linear's backward, e.g. for transformer.py:125-133's Linears):
  * C[M,N] = A[M,K] * B[K,N] (+ bias[N] for SEDD_EPI_BIAS) — "NN": B's reduction index is the row, so no transposed

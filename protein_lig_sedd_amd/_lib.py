@@ -52,6 +52,7 @@ SIGNATURES = {
     "sedd_gemm_tn": "plplpliiilllplp",
     "sedd_gemm_nt_dgelu": "plplpliipplllp",
     "sedd_gemm_nn": "plplpliipilllp",
+    "sedd_gemm_nt_rotary": "plplpliipippiiilllp",
     "sedd_gemm_nn_dgelu": "plplpliipplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",

@@ -328,7 +328,11 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 //   path's stage layout and transposing reads, but A's fragments hold k = 8g..8g+7 in natural order, so lane group g
 //   addresses rows 8g+q and 8g+4+q instead, and the bank swizzle keys on row bits {0,1,3} (rows 8g+q, g = 0,1 of one
 //   half-wave must land in 8 distinct 32-byte bank groups).
-template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false>
+// ROT = true (sedd_gemm_nt_rotary): the output is a packed qkv [M, 3, H, 64] and the NeoX rotary rotation of
+//   rotary.py:42-51 is applied to its q and k columns in the epilogue — a wave's 64 output columns are exactly one
+//   head, and the pair (j, j + 32) sits in fragments n and n + 2 of the same lane.
+struct RotArgs { const float* cos; const float* sin; int L; int64_t cols; };  // tables [L, 32]; cols = 2 * H * 64
+template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false, bool ROT = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
@@ -337,7 +341,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             TO* __restrict__ pre, int accumulate, int64_t M,
                                                             int64_t N, int64_t Kper, int64_t Ktot, int ntn,
                                                             int ntiles, int splitk, float4* __restrict__ slabs,
-                                                            float* __restrict__ colsum) {
+                                                            float* __restrict__ colsum, RotArgs rot) {
     constexpr int WN = BN_ / 64, WM = NW / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
     constexpr int LA = BIG_BM / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
     constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;                 // K-loop unroll: whole ring turns, even
@@ -610,6 +614,25 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         }
                 }
             } else {
+            // ROT: the cos / sin rows of pass p+RPD are requested while pass p is rotated, staged and stored
+            constexpr int RPD = 2;
+            float4 rc[ROT ? RPD : 1][2], rs[ROT ? RPD : 1][2];
+            const bool rot_on = ROT && col_w < rot.cols;  // (wave-uniform) a q or k head
+#define ROT_LOAD(pass_)                                                                                              \
+    do {                                                                                                             \
+        const int64_t rr_ = row_t + (pass_) * 16 + (lane & 15);                                                      \
+        const int l_ = (int)((rr_ < M ? rr_ : M - 1) % rot.L);                                                       \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                           \
+            rc[(pass_) % RPD][nb] = *reinterpret_cast<const float4*>(rot.cos + (int64_t)l_ * 32 + 4 * (lane >> 4) + nb * 16); \
+            rs[(pass_) % RPD][nb] = *reinterpret_cast<const float4*>(rot.sin + (int64_t)l_ * 32 + 4 * (lane >> 4) + nb * 16); \
+        }                                                                                                            \
+    } while (0)
+            if constexpr (ROT) {
+                if (rot_on) {
+#pragma unroll
+                    for (int p0 = 0; p0 < RPD && p0 < TM; ++p0) ROT_LOAD(p0);
+                }
+            }
 #pragma unroll
             for (int pass = 0; pass < TM / FPP; ++pass) {
                 const int64_t row_w = row_t + pass * SC::RPP;
@@ -638,6 +661,25 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                             v[0] += bv[n].x; v[1] += bv[n].y; v[2] += bv[n].z; v[3] += bv[n].w;
                         }
                 }
+                if constexpr (ROT) {
+                    static_assert(FPP == 1, "one 16-row fragment per pass");
+                    if (rot_on) {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const float4 c4 = rc[pass % RPD][nb], s4 = rs[pass % RPD][nb];
+                            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                            f32x4& lo = acc[pass][nb];
+                            f32x4& hi = acc[pass][nb + 2];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {  // the Linear's output is rounded to the activation dtype first
+                                const float x1 = to_f32<TO>(from_f32<TO>(lo[r])), x2 = to_f32<TO>(from_f32<TO>(hi[r]));
+                                lo[r] = x1 * cc[r] - x2 * ss[r];
+                                hi[r] = x2 * cc[r] + x1 * ss[r];
+                            }
+                        }
+                        if (pass + RPD < TM) ROT_LOAD(pass + RPD);
+                    }
+                }
 #pragma unroll
                 for (int mm = 0; mm < FPP; ++mm)
 #pragma unroll
@@ -645,6 +687,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), acc[pass * FPP + mm][n]);
                 stage_flush<TO>(reg, C, ldc, row_w, col_w, M, N, lane, 0);
             }
+#undef ROT_LOAD
             }
         }
         if (next >= ntiles) break;
@@ -857,9 +900,12 @@ static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
     *kper = per * BIG_BK;
 }
 
+static const RotArgs kNoRot{nullptr, nullptr, 1, 0};
+
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                         int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
-                        int64_t K, float* colsum, sedd_stream_t stream, bool b_kn = false) {
+                        int64_t K, float* colsum, sedd_stream_t stream, bool b_kn = false,
+                        const RotArgs* rot = nullptr) {
     SEDD_CHECK_ARG((in_dtype == SEDD_F32 || in_dtype == SEDD_BF16) && (out_dtype == SEDD_F32 || out_dtype == SEDD_BF16),
                    "gemm_nt: bad dtype");
     if (b_kn) {  // B given as [K, N] (NN form): bf16 big-tile kernel only
@@ -908,6 +954,9 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             const double c256 = (double)((t256 + 255) / 256) * 2.0, c128 = (double)((t128 + 255) / 256) * 1.15;
             bool wide = N > 128 && c256 <= c128;
             if (getenv("SEDD_GEMM_WIDE") && N > 128) wide = atoi(getenv("SEDD_GEMM_WIDE")) != 0;  // (A/B experiments)
+            // rotary epilogue: the 128-wide tile has the registers to keep two passes of cos / sin rows in flight (the
+            // 256-wide one spills with even one); same-box A/B at N = 2304: equal step time, so the narrow tile it is
+            if (rot) wide = false;
             const int bn = wide ? 256 : 128;
             const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
             int64_t kper = K;
@@ -919,24 +968,29 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \
-                       (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum)
+                       (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum, kNoRot)
 #define BIG_LAUNCH_X(BN_, DG_, NNB_)                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, BN_, 4, false, DG_, 8, NNB_>), g2, dim3(512), 0, st,            \
                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre,   \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum)
-            if (b_kn) {
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum, kNoRot)
+            if (rot) {
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, false, 8, false, true>), g2, dim3(512), 0,
+                                       st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
+                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
+                                       (float4*)nullptr, colsum, *rot);
+            } else if (b_kn) {
                 if (epilogue == EPI_DGELU) { if (wide) BIG_LAUNCH_X(256, true, true); else BIG_LAUNCH_X(128, true, true); }
                 else { if (wide) BIG_LAUNCH_X(256, false, true); else BIG_LAUNCH_X(128, false, true); }
             } else if (epilogue == EPI_DGELU && wide) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 256, 4, false, true>), g2, dim3(512), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)nullptr, colsum);
+                                       (float4*)nullptr, colsum, kNoRot);
             } else if (epilogue == EPI_DGELU) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, true>), g2, dim3(512), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)nullptr, colsum);
+                                       (float4*)nullptr, colsum, kNoRot);
             } else if (out_dtype == SEDD_BF16) {
                 static const int nw4 = getenv("SEDD_GEMM_NW4") ? atoi(getenv("SEDD_GEMM_NW4")) : 0;
                 if (nw4 && splitk == 1 && (nw4 == 2 || !wide)) {
@@ -946,7 +1000,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 3, false, false, 4>), g4, dim3(256), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn4, (int)tiles4, 1,
-                                       (float4*)nullptr, colsum);
+                                       (float4*)nullptr, colsum, kNoRot);
                 } else if (wide) BIG_LAUNCH(bf16_t, 256, 4);
                 else BIG_LAUNCH(bf16_t, 128, 4);
             } else {
@@ -1011,6 +1065,26 @@ extern "C" int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int
                         K, colsum, stream);
 }
 
+// The QKV projection with the rotary position embedding applied in the epilogue (transformer.py:165-171: attn_qkv,
+// rearrange to [b, s, 3, h, d], rotary.apply_rotary_pos_emb): C = packed qkv [M, 3*H*64] bf16, rows are tokens of
+// sequences of length L (position = row % L), cos / sin fp32 [L, 32].  The V columns pass through.
+extern "C" int sedd_gemm_nt_rotary(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                   int in_dtype, int out_dtype, const float* bias, int epilogue, const float* cos,
+                                   const float* sin, int L, int H, int d, int64_t M, int64_t N, int64_t K,
+                                   sedd_stream_t stream) {
+    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == SEDD_EPI_BIAS, "gemm_nt_rotary: bad epilogue %d", epilogue);
+    SEDD_CHECK_ARG(cos && sin && L > 0 && H > 0, "gemm_nt_rotary: bad rotary arguments");
+    if (in_dtype != SEDD_BF16 || out_dtype != SEDD_BF16 || d != 64 || N != (int64_t)3 * H * d || K % BIG_BK || M < 192 ||
+        M % L || (ldc * 2) % 16 || ((uintptr_t)C & 15)) {
+        sedd_set_error("gemm_nt_rotary: unsupported (bf16, head dim 64, N == 3*H*64, K %% 32 == 0, M >= 192, M %% L == 0, "
+                       "16-byte aligned C rows); use sedd_gemm_nt + sedd_rotary_qkv");
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    const RotArgs rot{cos, sin, L, (int64_t)2 * H * d};
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, nullptr, 0, M, N, K, nullptr, stream,
+                        false, &rot);
+}
+
 // C[M,N] = A[M,K] * B[K,N] (bf16): the data gradient of nn.Linear against the weight as stored (dX = dY W, W [out, in]),
 // no transposed weight copy.  epilogue: SEDD_EPI_NONE or SEDD_EPI_BIAS.
 extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
@@ -1071,7 +1145,7 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
 #define TN_LAUNCH(TO, BN_)                                                                                           \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, (float*)nullptr)
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, (float*)nullptr, kNoRot)
     if (out_dtype == SEDD_BF16) {
         if (wide) TN_LAUNCH(bf16_t, 256);
         else TN_LAUNCH(bf16_t, 128);

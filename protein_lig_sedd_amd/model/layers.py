@@ -174,8 +174,12 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
     mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 6D]
     w1, w2 = P["norm1.weight"].detach(), P["norm2.weight"].detach()
     h1, mean1, rstd1 = ops.ln_modulate_fwd(x, w1, shift=mod[:, :D], scale=mod[:, D:2 * D], out_dtype=cdt)
-    qkv = linear_fwd(h1.view(M, D), P["attn_qkv.weight"]).view(B, L, 3, H, d)
-    ops.rotary_qkv_(qkv, cos, sin)
+    Wqkv = compute_weight(P["attn_qkv.weight"], cdt)
+    if ops.gemm_nt_rotary_supported(h1.view(M, D), Wqkv, L, H, d):  # rotary rides in the projection's epilogue
+        qkv = ops.gemm_nt_rotary(h1.view(M, D), Wqkv, cos, sin, L, H, d).view(B, L, 3, H, d)
+    else:
+        qkv = linear_fwd(h1.view(M, D), P["attn_qkv.weight"]).view(B, L, 3, H, d)
+        ops.rotary_qkv_(qkv, cos, sin)
     o, lse = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
     a = linear_fwd(o.view(M, D), P["attn_out.weight"]).view(B, L, D)
     inv = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0

@@ -489,6 +489,31 @@ def gemm_nt_dgelu(A, B, pre, colsum=None):
     return out
 
 
+def gemm_nt_rotary_supported(A, B, L, H, d):
+    M, K = A.shape
+    return (not os.environ.get("SEDD_NO_GEMM_ROTARY") and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+            and d == 64 and B.shape[0] == 3 * H * d and K % 32 == 0 and M >= 192 and M % L == 0
+            and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nt_rotary(A, B, cos, sin, L, H, d, bias=None):
+    """packed qkv [M, 3*H*d] = A[M,K] @ B[3*H*d, K]^T (+bias) with rotary applied to the q and k columns
+    (position = row % L; cos / sin compact fp32 [L, d/2])."""
+    M, K = A.shape
+    N = B.shape[0]
+    if cos.shape != (L, d // 2) or sin.shape != cos.shape or cos.dtype != torch.float32 or not cos.is_contiguous() \
+            or not sin.is_contiguous():
+        raise ValueError("gemm_nt_rotary: cos / sin must be contiguous fp32 [L, d/2]")
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    epi = _L.EPI_NONE if bias is None else _L.EPI_BIAS
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(lib().sedd_gemm_nt_rotary(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                        _p(bias), epi, _p(cos), _p(sin), L, H, d, M, N, K, _stream()),
+              "sedd_gemm_nt_rotary")
+    return out
+
+
 def gemm_nn_supported(A, B):
     """whether sedd_gemm_nn / sedd_gemm_nn_dgelu take A [M, K] @ B [K, N] (else: transposed copy of B + gemm_nt)."""
     if os.environ.get("SEDD_NO_GEMM_NN"):

@@ -154,6 +154,28 @@ def test_gemm_nn_rejects_unsupported():
         ops.gemm_nn(A, torch.zeros(32, 104, device=DEV).bfloat16()[:, :100])
 
 
+@pytest.mark.parametrize("Bt,L,H,K", [(4, 128, 12, 768), (2, 100, 3, 96), (64, 512, 12, 768)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_gemm_nt_rotary_matches_gemm_then_rotary(Bt, L, H, K, with_bias):
+    """QKV projection with rotary in the epilogue == sedd_gemm_nt followed by sedd_rotary_qkv (transformer.py:165-171)."""
+    ops = _ops()
+    d, M = 64, Bt * L
+    torch.manual_seed(L + H)
+    A = (0.5 * torch.randn(M, K, device=DEV)).bfloat16()
+    W = (0.2 * torch.randn(3 * H * d, K, device=DEV)).bfloat16()
+    bias = torch.randn(3 * H * d, device=DEV) if with_bias else None
+    ang = torch.rand(L, d // 2, device=DEV) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    assert ops.gemm_nt_rotary_supported(A, W, L, H, d)
+    got = ops.gemm_nt_rotary(A, W, cos, sin, L, H, d, bias=bias).view(Bt, L, 3, H, d)
+    ref = ops.gemm_nt(A, W, bias=bias).view(Bt, L, 3, H, d).clone()
+    assert torch.equal(got[:, :, 2], ref[:, :, 2])            # V passes through
+    ops.rotary_qkv_(ref, cos, sin)
+    # same fp32 arithmetic on the same bf16-rounded projection; fma contraction may move the last bf16 bit
+    assert rel_err(got.float(), ref.float()) < 4e-3
+    assert float((got.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     from protein_lig_sedd_amd._lib import SeddError
