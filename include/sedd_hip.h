@@ -183,6 +183,10 @@ int sedd_transpose(const void* a, int a_dtype, int64_t lda, void* out, int out_d
                    int64_t N, sedd_stream_t stream);
 /* elementwise cast fp32 <-> bf16, n elements. */
 int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, sedd_stream_t stream);
+/* x[i] *= scale[0] (scale: one fp32 on the device; product in fp32, rounded to x's dtype; x 16-byte aligned): the
+ * upstream gradient of the scalar loss (losses.py:29 `.mean()` / the trainer's `loss.backward()`) applied to the
+ * log-score gradient without a host read of the scalar. */
+int sedd_scale_(void* x, int dtype, const float* scale, int64_t n, sedd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------- GEMM
  * nn.Linear (transformer.py:125-134,140,225,229; transformers_protlig_cross.py:250-268):

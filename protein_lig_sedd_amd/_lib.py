@@ -48,6 +48,7 @@ SIGNATURES = {
     "sedd_colsum": "pilpilip",
     "sedd_transpose": "pilpilllp",
     "sedd_cast": "pipilp",
+    "sedd_scale_": "piplp",
     "sedd_gemm_nt": "plplpliipipilllp",
     "sedd_gemm_tn": "plplpliiilllplp",
     "sedd_gemm_nt_dgelu": "plplpliipplllp",

@@ -1046,3 +1046,28 @@ extern "C" int sedd_cast(const void* in, int in_dtype, void* out, int out_dtype,
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
+
+// ============================================================================================ scale by a device scalar
+// x *= *s (fp32 product, rounded to x's type): the upstream gradient of the scalar loss applied to the gradient the
+// fused loss kernel produced in its forward pass (losses.py:29's .mean() backward), without reading *s on the host.
+template <typename T>
+__global__ void __launch_bounds__(TPB) scale_kernel(T* __restrict__ x, const float* __restrict__ s, int64_t n) {
+    const float f = s[0];
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        const float4 v = load4<T>(x + i * 4);
+        store4<T>(x + i * 4, make_float4(v.x * f, v.y * f, v.z * f, v.w * f));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+        x[nv * 4 + threadIdx.x] = from_f32<T>(to_f32<T>(x[nv * 4 + threadIdx.x]) * f);
+}
+extern "C" int sedd_scale_(void* x, int dtype, const float* scale, int64_t n, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(dt_ok(dtype), "scale_: bad dtype");
+    SEDD_CHECK_ARG(n >= 0, "scale_: bad size");
+    if (n == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(x && scale && ((uintptr_t)x & 15) == 0, "scale_: null or unaligned pointer");
+    const dim3 grid(sedd_grid_for(n / 4 + 1, TPB, 256 * 16));
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((scale_kernel<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (T*)x, scale, n));
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}

@@ -27,10 +27,10 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (ds,) = ctx.saved_tensors
-        # gout is the scalar upstream gradient (1 for loss.backward()); scaling by it is a [1] x tensor op
-        if gout.numel() == 1 and float(gout) == 1.0:
-            return ds, None, None, None, None, None
-        return ds * gout.to(ds.dtype), None, None, None, None, None
+        # gout is the scalar upstream gradient (1 for loss.backward()): applied on the device — reading it on the host
+        # would stall the launch queue at the start of every backward pass
+        ds = ops.scale_(ds.clone(), gout.detach().reshape(1).float())  # (the saved tensor stays intact for a re-run)
+        return ds, None, None, None, None, None
 
 
 def get_loss_fn(noise, graph, train=True, sampling_eps=1e-3, lv=False, fused=True):

@@ -663,6 +663,14 @@ def ema_update_(shadow, p, one_minus_decay):
     return shadow
 
 
+def scale_(x, s):
+    """x *= s in place, s a 1-element fp32 device tensor (never read on the host)."""
+    if s.dtype != torch.float32 or s.numel() != 1 or not x.is_contiguous():
+        raise ValueError("scale_: contiguous x and a 1-element fp32 scale")
+    check(lib().sedd_scale_(_p(x), _dt(x), _p(s), x.numel(), _stream()), "sedd_scale_")
+    return x
+
+
 def batch_weighted_sum(x, w):
     """x fp32 [B, L], w fp32 [B] -> 0-dim fp32 tensor sum_b w_b * sum_l x[b, l]."""
     B = x.shape[0]
