@@ -176,7 +176,10 @@ def main():
     for i in range(args.warmup):
         trainer.train_step(batches[i % 4])
     sync()
-    ops.PROF = ops.KernelProf()
+    # HIP events on the launch stream around every 5th launch of each kernel family (5 is coprime to the 186 GEMM
+    # launches of a step, so over the timed steps every launch position is sampled equally often); bracketing every
+    # launch costs 1.2 ms per step (tools/event_overhead.py)
+    ops.PROF = ops.KernelProf(stride=5)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.train_step(batches[i % 4])
@@ -234,6 +237,7 @@ def main():
                          "traffic_source": "profiles/r1f_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
                                            "rocprofv3 --pmc passes of this command, average over the bf16 GEMM launches)",
                          "launches_per_step": n_g / max(args.steps, 1),
+                         "timed_sample": "HIP events around every 5th launch of the family, scaled to all launches",
                          "avg_launch_us": 1e3 * ms_g / max(n_g, 1),
                          "gemm_ms_per_step": ms_g / max(args.steps, 1)},
             "kernels": others,

@@ -9,20 +9,31 @@ from ._lib import ABSORB, BF16, F32, UNIFORM, check, lib  # noqa: F401
 
 
 class KernelProf:
-    """Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figures)."""
+    """Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline figures).
+    stride > 1 times every stride-th launch of each family only: an event pair costs ~3 us of stream time (the
+    launches on either side can no longer overlap), 1.2 ms per cfg-2 step when every launch is bracketed."""
 
-    def __init__(self):
-        self.recs = {}
+    def __init__(self, stride=1):
+        self.stride = max(int(stride), 1)
+        self.recs, self.seen = {}, {}
+
+    def want(self, name):
+        n = self.seen.get(name, 0)
+        self.seen[name] = n + 1
+        return n % self.stride == 0
 
     def add(self, name, start, end, work):
         self.recs.setdefault(name, []).append((start, end, work))
 
     def summary(self):
-        """name -> (launches, total ms, total work); call after a device synchronize."""
+        """name -> (launches seen, estimated total ms, total work): the timed sample scaled to all launches; call
+        after a device synchronize."""
         out = {}
         for name, rs in self.recs.items():
             ms = sum(s.elapsed_time(e) for s, e, _ in rs)
-            out[name] = (len(rs), ms, sum(w for _, _, w in rs))
+            work = sum(w for _, _, w in rs)
+            k = self.seen[name] / len(rs)
+            out[name] = (self.seen[name], ms * k, work * k)
         return out
 
 
@@ -32,16 +43,18 @@ PROF = None  # set to a KernelProf to time instrumented launches
 class _Timed:
     def __init__(self, name, work):
         self.name, self.work = name, work
+        self.on = False
 
     def __enter__(self):
-        if PROF is not None:
+        if PROF is not None and PROF.want(self.name):
+            self.on = True
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *a):
-        if PROF is not None:
+        if self.on:
             self.e.record()
             PROF.add(self.name, self.s, self.e, self.work)
         return False
