@@ -92,7 +92,7 @@ def cpu_baseline(seconds_budget=12.0):
 
 # average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
 # prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r1f_pmc_hbm_traffic.csv
-GEMM_HBM_BYTES_PER_LAUNCH = 290.6e6
+GEMM_HBM_BYTES_PER_LAUNCH = 296.0e6
 
 
 def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
