@@ -115,7 +115,12 @@ class SEDDTrainer:
         # SEDD_DP_FORCE=1 runs every collective of the N > 1 path over a 1-rank group (rehearsal of the RCCL stream
         # ordering on a single GPU); SEDD_DP_OVERLAP=0 falls back to one blocking all-reduce after backward
         self.dp = self.world > 1 or (os.environ.get("SEDD_DP_FORCE") == "1" and dist.is_initialized())
-        self.overlap = overlap and self.dp and os.environ.get("SEDD_DP_OVERLAP", "1") != "0"
+        # The per-block overlapped all-reduce is OPT-IN (SEDD_DP_OVERLAP=1).  The GEMMs of this path are persistent, one
+        # 512-thread block per CU holding the CU's whole register file; a CU that hosts an RCCL workgroup cannot take a
+        # GEMM block, so every GEMM launched while a collective is resident waits for a second round of its blocks
+        # (2x its time).  One all-reduce of the flat gradient buffer after backward (~1.9 ms at 8 GPUs for 370 MB)
+        # costs less than that and nothing at all at N = 1.
+        self.overlap = overlap and self.dp and os.environ.get("SEDD_DP_OVERLAP", "0") == "1"
         self._pending = []
         self._buckets = self._make_buckets()
         if self.dp:

@@ -32,7 +32,9 @@ def _worker(rank, world, port, q):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(torch.randn_like(p) * 0.1)
+        os.environ["SEDD_DP_OVERLAP"] = "1"  # exercise the opt-in per-block overlapped path as well as the default
         tr = SEDDTrainer(model, noise_lib.LogLinearNoise(), graph_lib.Absorbing(25), dict(lr=1e-3), world_size=world)
+        assert tr.overlap
         fl = tr.flat
         # 1. broadcast: rank 0's parameters everywhere, params / grads are views of the flat buffers
         ref = [torch.empty_like(fl.p) for _ in range(world)]
