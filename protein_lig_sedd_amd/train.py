@@ -6,8 +6,9 @@ Design (one process per GPU, torch.distributed backend "nccl" == RCCL over xGMI)
   * all parameters live in ONE flat fp32 buffer (each tensor padded to 64 elements); gradients, Adam moments, the EMA
     shadow and the bf16 compute copy are flat buffers of the same layout.  param.data / param.grad are views, so the
     backward kernels accumulate weight gradients straight into the flat gradient buffer;
-  * the gradient buffer is all-reduced in per-block buckets that are launched asynchronously as soon as a block's
-    backward has finished (overlaps RCCL with the remaining backward), then one deterministic norm reduction, then
+  * the gradient buffer is all-reduced in ONE RCCL call after backward (default), or — opt-in, SEDD_DP_OVERLAP=1 — in
+    per-block buckets launched asynchronously as soon as a block's backward has finished (see SEDDTrainer.__init__
+    for why that is not the default with persistent one-block-per-CU GEMMs); then one deterministic norm reduction, then
     ONE fused kernel does clip -> AdamW -> EMA -> bf16 weight copy over the whole model (sedd_adamw_ema_step) instead
     of the reference's per-parameter optimizer / EMA loops;
   * no DDP wrapper, no GradScaler (bf16 needs no loss scaling; the reference's scaler is a no-op numerically).
@@ -86,7 +87,7 @@ def init_distributed():
 
 
 class SEDDTrainer:
-    """loss_fn(model, batch) -> backward -> bucketed RCCL all-reduce -> fused clip/AdamW/EMA step.
+    """loss_fn(model, batch) -> backward -> RCCL all-reduce of the flat gradient buffer -> fused clip/AdamW/EMA step.
 
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
