@@ -54,6 +54,41 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float u) {
     const float t = tanhf(0.7978845608028654f * (u + 0.044715f * u * u * u));
     return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * u * u);
 }
+// Four elements at a time in the bf16 epilogues, written on ext-vector types so the polynomial parts compile to packed
+// fp32 ops (v_pk_mul/fma/add_f32, two elements per instruction): with s = sigmoid(2a) = 1 / (1 + 2^(u (A + B u^2))),
+// gelu_tanh(u) = u s and gelu_tanh'(u) = s (1 + u (1 - s)(C + D u^2)) — 5 resp. 9 plain operations + exp2 + rcp per
+// element instead of ~12 / ~22 through tanh (the fused dGELU epilogue is VALU-bound: every wave of the block is in it at
+// the same time, nothing overlaps it).  fp32 outputs keep the exact tanhf forms.
+template <typename TO> __device__ __forceinline__ f32x4 gelu4_t(f32x4 u) {
+    if constexpr (sizeof(TO) == 2) {
+        const f32x4 z = u * (-2.3022082f + -0.10294324f * (u * u));
+        f32x4 s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[r]));
+        return u * s;
+    } else {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = gelu_tanh_t<TO>(u[r]);
+        return o;
+    }
+}
+template <typename TO> __device__ __forceinline__ f32x4 gelu_grad4_t(f32x4 u) {
+    if constexpr (sizeof(TO) == 2) {
+        const f32x4 u2 = u * u;
+        const f32x4 z = u * (-2.3022082f + -0.10294324f * u2);
+        f32x4 s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[r]));
+        const f32x4 w = u * (1.5957691216f + 0.21406445f * u2);
+        return s + s * (w * (1.0f - s));
+    } else {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = gelu_tanh_grad_t<TO>(u[r]);
+        return o;
+    }
+}
 #define EPI_DGELU 3  // internal (sedd_gemm_nt_dgelu): C = (A B^T) * gelu_tanh'(pre), pre is an INPUT, column sums out
 
 // bijective XCD-aware remap (8 XCDs): blocks that share an XCD get a contiguous range of tiles
@@ -94,8 +129,7 @@ __device__ __forceinline__ void epilogue4(TO* __restrict__ C, int64_t ldc, TO* _
             else
                 for (int r = 0; r < 4 && col + r < N; ++r) pp[r] = from_f32<TO>(v[r]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_t<TO>(v[r]);
+        v = gelu4_t<TO>(v);
     }
     if (accumulate) {
         if constexpr (sizeof(TO) == 4) {
@@ -585,11 +619,13 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         union { uint2 u; TO e[4]; } pv;
                         pv.u = *reinterpret_cast<const uint2*>(reg + (lane & 15) * SC::PITCH + (n * 16 + 4 * (lane >> 4)) * sizeof(TO));
                         f32x4& v = acc[pass][n];
+                        const f32x4 gp = gelu_grad4_t<TO>((f32x4){to_f32<TO>(pv.e[0]), to_f32<TO>(pv.e[1]),
+                                                                  to_f32<TO>(pv.e[2]), to_f32<TO>(pv.e[3])});
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // the reference rounds the Linear's data gradient to the activation dtype before GELU's
                             const float dy = to_f32<TO>(from_f32<TO>(v[r]));
-                            v[r] = to_f32<TO>(from_f32<TO>(dy * gelu_tanh_grad_t<TO>(to_f32<TO>(pv.e[r]))));
+                            v[r] = to_f32<TO>(from_f32<TO>(dy * gp[r]));
                             cs[n][r] += rok ? v[r] : 0.f;
                         }
                     }
@@ -648,8 +684,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                             v[2] = to_f32<TO>(from_f32<TO>(v[2] + bv[n].z));
                             v[3] = to_f32<TO>(from_f32<TO>(v[3] + bv[n].w));
                             if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), v);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_t<TO>(v[r]);
+                            v = gelu4_t<TO>(v);
                         }
                     if (pre) stage_flush<TO>(reg, pre, ldc, row_w, col_w, M, N, lane, 0);
                 } else if (epi == SEDD_EPI_BIAS) {
