@@ -68,3 +68,35 @@ def test_bf16_training_reduces_loss():
     assert all(l == l and abs(l) < 1e4 for l in losses)
     assert losses[-1] < losses[0]
     assert torch.equal(tr.flat.pc, tr.flat.p.bfloat16())
+
+
+@pytest.mark.parametrize("cdt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_large_config_dims_match_the_oracle(cdt, tol):
+    """BASELINE configs[3] dimensions (D 1024, 16 heads of 64, cond 128, L 1024; 2 blocks, batch 2 to keep the CPU oracle
+    quick): loss and every weight gradient of one step against the oracle — exercises the wide LayerNorm / GEMM tile /
+    long-sequence attention paths that the cfg-2 goldens do not reach."""
+    from oracle import sedd_cpu as O
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.losses import get_loss_fn
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    D, H, C, nb, tokens, B, L = 1024, 16, 128, 2, 25, 2, 1024
+    torch.manual_seed(5)
+    model = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=21)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    x0, t, u = torch.randint(0, tokens, (B, L)), torch.rand(B) * 0.9 + 0.05, torch.rand(B, L)
+    og, on = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
+    xt = og.sample_transition(x0, on(t)[0][:, None], u)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, _ = O.sedd_loss(sdr, og, on, x0, t, xt, H, nb)
+    ref_loss.backward()
+    loss = get_loss_fn(noise, graph, train=True)(model, x0.to(DEV), t=t.to(DEV), perturbed_batch=xt.to(DEV))
+    loss.backward()
+    assert_close(loss, ref_loss.detach(), tol, 0, "loss")
+    for k in ("blocks.0.attn_qkv.weight", "blocks.1.mlp.2.weight", "blocks.0.adaLN_modulation.weight",
+              "blocks.1.norm2.weight", "output_layer.linear.weight", "vocab_embed.embedding.weight"):
+        p = dict(model.named_parameters())[k]
+        ref = sdr[k].grad
+        err = float((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert err < (2e-4 if cdt == torch.float32 else 5e-2), f"{k}: relative gradient error {err:.3e}"
