@@ -564,6 +564,33 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     dst[(m * 4 + n) * 64] = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+        } else if (sizeof(TO) == 4 && accumulate && splitk == 1 && vec_ok && epi == SEDD_EPI_NONE) {
+            // C += tile (weight gradients with a short reduction, e.g. adaLN: K = batch): the old values of a fragment
+            // row are requested four fragments at a time — one load-add-store chain per fragment serialises 32 memory
+            // round trips per lane, which at K = 64 was the whole kernel (29 us)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int64_t row = row_t + m * 16 + (lane & 15);
+                float4 old[4];
+                bool ok[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int64_t col = col_w + n * 16 + 4 * (lane >> 4);
+                    ok[n] = row < M && col + 4 <= N;
+                    old[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok[n]) old[n] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(C) + row * ldc + col);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int64_t col = col_w + n * 16 + 4 * (lane >> 4);
+                    if (ok[n])
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + row * ldc + col) =
+                            make_float4(old[n].x + acc[m][n][0], old[n].y + acc[m][n][1], old[n].z + acc[m][n][2],
+                                        old[n].w + acc[m][n][3]);
+                    else
+                        epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, 0, row, col, M, N, acc[m][n], vec_ok);
+                }
+            }
         } else if (!staged) {  // fp32 / split-K atomics / accumulate / unaligned C: straight from the accumulators
 #pragma unroll
             for (int m = 0; m < TM; ++m)
