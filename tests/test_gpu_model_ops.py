@@ -332,7 +332,7 @@ def test_gelu_silu_embed_epilogue_colsum_transpose():
     sig = torch.rand(9, device=DEV) * 7
     assert_close(ops.timestep_embedding(sig, 256), O.timestep_embedding(sig.cpu()), 1e-5, 2e-6)
     # embedding fwd / scatter-add bwd (small and large vocab)
-    for V in (26, 2365):
+    for V in (26, 32, 38, 2365):  # (<= 32: per-wave LDS slices; <= 64: LDS atomics; larger: global atomics)
         tab = torch.randn(V, 768, device=DEV)
         idx = torch.randint(0, V, (5, 333), device=DEV)
         assert torch.equal(ops.embedding_fwd(tab, idx), tab[idx])
