@@ -457,7 +457,8 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     S[mt][tt] = mma_rows<T, D>(kf, qf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-                    dP[mt][tt] = mma_rows<T, D>(vf, dof[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    // the accumulator starts at -delta of the lane's query: dP - delta comes out of the MFMA
+                    dP[mt][tt] = mma_rows<T, D>(vf, dof[mt], (f32x4){-dl[mt], -dl[mt], -dl[mt], -dl[mt]});
                 }
             }
 #pragma unroll
@@ -472,7 +473,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         const float p = valid ? fast_exp2(fmaf(S[mt][tt][r], sl2, -lq[mt])) : 0.f;
-                        S[mt][tt][r] = p * (dP[mt][tt][r] - dl[mt]);  // dS^T / scale
+                        S[mt][tt][r] = p * dP[mt][tt][r];  // dS^T / scale
                     }
                 }
             mma_tr_pair<T, D>(acc[0], acc[1], Ks, hh, S[0][0], S[0][1], S[1][0], S[1][1], lane);
@@ -557,16 +558,16 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
                 const int t = 2 * hh + tt;
                 const RowFrag<T, D> qf = load_rowfrag<T, D>(Qs + (16 * t + i) * LS, g);
                 const RowFrag<T, D> dof = load_rowfrag<T, D>(dOs + (16 * t + i) * LS, g);
+                const f32x4 ndl4 = -*reinterpret_cast<const f32x4*>(&del_s[16 * t + 4 * g]);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {  // C/D: col = own key (lane & 15), row = query 16t + 4g + reg
                     S[mt][tt] = mma_rows<T, D>(qf, kf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
-                    dP[mt][tt] = mma_rows<T, D>(dof, vf[mt], (f32x4){0.f, 0.f, 0.f, 0.f});
+                    dP[mt][tt] = mma_rows<T, D>(dof, vf[mt], ndl4);  // starts at -delta: dP - delta comes out of the MFMA
                 }
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const f32x4 lq4 = *reinterpret_cast<const f32x4*>(&lse_s[16 * (2 * hh + tt) + 4 * g]);
-                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(&del_s[16 * (2 * hh + tt) + 4 * g]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -574,7 +575,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
                         float p = fast_exp2(fmaf(S[mt][tt][r], sl2, -lq4[r]));
                         if constexpr (!PLAIN) p = kvalid[mt] ? p : 0.f;
                         S[mt][tt][r] = p;                            // P
-                        dP[mt][tt][r] = p * (dP[mt][tt][r] - dl4[r]);  // dS / scale
+                        dP[mt][tt][r] = p * dP[mt][tt][r];  // dS / scale
                     }
             }
             mma_tr_pair<T, D>(adv[0], adv[1], dOs, hh, S[0][0], S[0][1], S[1][0], S[1][1], lane);
