@@ -87,7 +87,75 @@ def cpu_baseline(seconds_budget=12.0):
         n += 1
     dt = time.perf_counter() - t0
     return {"value": B * L * n / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of the same model at batch {B} x L {L}, fp32, oracle/sedd_cpu.py + AdamW/EMA"}
+            "sample": f"{n} train steps of the same model at batch {B} x L {L}, fp32, oracle/sedd_cpu.py + AdamW/EMA",
+            "cfg1": cpu_baseline_cfg1()}
+
+
+def cpu_baseline_cfg1(euler_steps_timed=12):
+    """BASELINE configs[0] — the reference's own CPU-runnable case (tiny SEDD: D768 x 8 blocks, 8 heads of 96, L=128,
+    batch 8, V=26, fp32): one oracle train step (fwd + bwd + clip + AdamW + EMA) and the 128-step Euler sampler + denoise
+    (SURVEY 8d), on all host threads torch uses here and on 8 threads (the survey container measured 1.19 s / 34.9 s on
+    8 cores with the reference itself).  The sampler is timed on a bounded sample of its 129 model evaluations."""
+    from oracle import sedd_cpu as O
+    from oracle.weights import seeded_state_dict
+    D, H, C, nb, tokens, B, L = 768, 8, 128, 8, 25, 8, 128
+    shapes = {"vocab_embed.embedding.weight": (tokens + 1, D), "sigma_map.mlp.0.weight": (C, 256),
+              "sigma_map.mlp.0.bias": (C,), "sigma_map.mlp.2.weight": (C, C), "sigma_map.mlp.2.bias": (C,),
+              "output_layer.norm_final.weight": (D,), "output_layer.linear.weight": (tokens + 1, D),
+              "output_layer.linear.bias": (tokens + 1,), "output_layer.adaLN_modulation.weight": (2 * D, C),
+              "output_layer.adaLN_modulation.bias": (2 * D,)}
+    for i in range(nb):
+        for k, v in {"norm1.weight": (D,), "norm2.weight": (D,), "attn_qkv.weight": (3 * D, D), "attn_out.weight": (D, D),
+                     "mlp.0.weight": (4 * D, D), "mlp.0.bias": (4 * D,), "mlp.2.weight": (D, 4 * D), "mlp.2.bias": (D,),
+                     "adaLN_modulation.weight": (6 * D, C), "adaLN_modulation.bias": (6 * D,)}.items():
+            shapes[f"blocks.{i}.{k}"] = v
+    sd = {k: v.requires_grad_(True) for k, v in seeded_state_dict(shapes, seed=0).items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    ema = {k: v.detach().clone() for k, v in sd.items()}
+    graph, noise = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
+
+    def train_step(s):
+        x0 = torch.randint(0, tokens, (B, L))
+        t = torch.rand(B) * 0.999 + 1e-3
+        xt = graph.sample_transition(x0, noise(t)[0][:, None], torch.rand(B, L))
+        for p in sd.values():
+            p.grad = None
+        loss, _ = O.sedd_loss(sd, graph, noise, x0, t, xt, H, nb)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values()))
+        coef = O.clip_coef(gn, 1.0)
+        with torch.no_grad():
+            for k, p in sd.items():
+                O.adamw_step(p, p.grad, m[k], v2[k], s, 3e-4, clip_coef=coef)
+                O.ema_update(ema[k], p, O.ema_decay(s, 0.9999))
+
+    def euler(nsteps_timed, total=128):
+        x = graph.sample_limit(B, L)
+        ts = torch.linspace(1, 1e-5, total + 1)
+        dt = (1 - 1e-5) / total
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(nsteps_timed):
+                sg = noise(ts[i] * torch.ones(B, 1))
+                x = O.euler_step(graph, O.sedd_forward(sd, x, sg[0].reshape(-1), H, nb), x, sg, dt, torch.rand(B, L, tokens + 1))
+        return (time.perf_counter() - t0) / nsteps_timed
+
+    out = {"workload": "BASELINE configs[0]: SEDD tiny D768 x 8 blocks, 8 heads, L=128, batch 8, V=26, fp32"}
+    default_threads = torch.get_num_threads()
+    for nthr in sorted({default_threads, min(8, default_threads)}, reverse=True):
+        torch.set_num_threads(nthr)
+        train_step(1)
+        t0 = time.perf_counter()
+        for s in range(3):
+            train_step(s + 2)
+        ts_ = (time.perf_counter() - t0) / 3
+        per_eval = euler(euler_steps_timed if nthr == default_threads else 4)
+        out[f"threads_{nthr}"] = {"train_step_s": ts_, "train_tokens_per_s": B * L / ts_,
+                                  "euler_128_steps_plus_denoise_s": per_eval * 129, "sampled_seqs_per_s": B / (per_eval * 129),
+                                  "sample": "3 train steps; sampler = per-evaluation time of the first Euler steps x 129"}
+    torch.set_num_threads(default_threads)
+    return out
 
 
 # average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
@@ -134,7 +202,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sample-steps", type=int, default=8, help="Analytic sampler steps timed for the seqs/s side metric")
+    ap.add_argument("--sample-steps", type=int, default=4, help="Analytic sampler steps timed for the seqs/s side metric")
+    ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU sampling shard (BASELINE configs[4]: 4096 / 8)")
+    ap.add_argument("--sample-seq", type=int, default=1024, help="sampled sequence length (BASELINE configs[4])")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints a version banner at communicator
     # creation) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the run and the JSON goes to
@@ -176,6 +246,7 @@ def main():
     for i in range(args.warmup):
         trainer.train_step(batches[i % 4])
     sync()
+    trainer.reset_allreduce_timing()
     # HIP events on the launch stream around every 5th launch of each kernel family (5 is coprime to the 186 GEMM
     # launches of a step, so over the timed steps every launch position is sampled equally often); bracketing every
     # launch costs 1.2 ms per step (tools/event_overhead.py)
@@ -187,18 +258,24 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.PROF.summary()
     ops.PROF = None
+    allreduce_ms = trainer.allreduce_ms_per_step()  # None unless the data-parallel path ran
     if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     tokens_per_s = world * B * L * args.steps / dt
 
-    # side metric: sampled sequences/s (Analytic predictor, batch = per-GPU shard, L = seq), bf16 model forward
+    # second half of the metric: sampled sequences/s at BASELINE configs[4] — the cfg-2 model, Analytic predictor, 1024
+    # steps, shape (4096, 1024) sharded 512 per GPU (sampling/run_sample_cond.py:40-42) — measured on `--sample-steps`
+    # timed sampler steps (+ the denoiser step) of exactly that per-GPU shard and scaled to the 1025 model evaluations of
+    # a full run; every step does the same work (bf16 model forward on 512 x 1024 tokens + one fused predictor kernel)
     samp = None
     if args.sample_steps > 0:
         model.eval()
-        sampler = sampling.get_pc_sampler(graph, noise, (B, L), "analytic", args.sample_steps, denoise=True, device=dev)
-        sampler(model)
+        SB, SL = args.sample_batch, args.sample_seq
+        sampler = sampling.get_pc_sampler(graph, noise, (SB, SL), "analytic", args.sample_steps, denoise=True, device=dev)
+        warm = sampling.get_pc_sampler(graph, noise, (SB, SL), "analytic", 1, denoise=True, device=dev)
+        warm(model)
         sync()
         ops.PROF = ops.KernelProf()
         t1 = time.perf_counter()
@@ -207,11 +284,23 @@ def main():
         ds = time.perf_counter() - t1
         sprof = ops.PROF.summary()
         ops.PROF = None
+        if multi:
+            tt = torch.tensor([ds], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ds = float(tt)
+        evals = args.sample_steps + 1
         n_l, ms_l, by_l = sprof.get("predictor_step", (0, 0.0, 0.0))
+        n_sg, ms_sg, fl_sg = sprof.get("gemm_bf16_nt", (0, 0.0, 0.0))
+        n_sa, ms_sa, fl_sa = sprof.get("attn_fwd", (0, 0.0, 0.0))
         hbm = hbm_kernels_cfg5(graph, dev)
-        samp = {"sampler_model_evals_per_s": world * (args.sample_steps + 1) / ds * B,
+        samp = {"workload": "BASELINE configs[4]: cfg-2 model, Analytic predictor, 1024 steps, per-GPU shard %d x %d, "
+                            "V=26, bf16 forward; timed on %d sampler steps + denoise, scaled to 1025 evaluations" % (SB, SL, args.sample_steps),
+                "ms_per_sampler_step": 1e3 * ds / evals,
+                "seqs_per_s_at_1024_steps": world * SB / (ds / evals * 1025),
+                "forward_tokens_per_s": world * SB * SL * evals / ds,
+                "gemm_ms_per_step": ms_sg / evals, "gemm_TFLOPs": fl_sg / max(ms_sg, 1e-9) / 1e9,
+                "attn_ms_per_step": ms_sa / evals, "attn_TFLOPs": fl_sa / max(ms_sa, 1e-9) / 1e9,
                 "hbm_kernels_at_cfg5_shard": hbm,
-                "seqs_per_s_at_1024_steps": world * B / (ds / (args.sample_steps + 1) * 1025),
                 "predictor_step": {"launches": n_l, "avg_us": 1e3 * ms_l / max(n_l, 1),
                                    "achieved_GBs": by_l / max(ms_l, 1e-9) / 1e6,
                                    "frac_hbm_peak": by_l / max(ms_l, 1e-9) / 1e6 / PEAK_HBM_GBS}}
@@ -229,6 +318,9 @@ def main():
                                    "bf16, per-GPU batch %d, AdamW+EMA, dropout 0.1, dp%d" % (B, world),
                        "global_batch": B * world, "seq_len": L, "params": nparams, "parallelism": f"dp{world}"},
             "loss": float(loss),
+            "dp": {"rccl_world_size": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
+                   "grad_bytes_per_step": 4 * trainer.flat.n, "allreduce_ms_per_step": allreduce_ms,
+                   "form": "per-block overlapped buckets" if trainer.overlap else "one all-reduce of the flat gradient buffer after backward"},
             "roofline": {"bound": "mfma",
                          "kernel": "gemm_bf16_big_kernel NT/TN (+ gemm_bf16_nt_glds_kernel for small shapes): every "
                                    "Linear fwd / dgrad / wgrad launch of the step",

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEDD_ABI_VERSION 1
+#define SEDD_ABI_VERSION 2
 
 typedef void* sedd_stream_t; /* hipStream_t */
 
@@ -126,6 +126,20 @@ int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const flo
                          const float* dx_add, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);
 int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float* dscale, int64_t dmod_stride,
                                 int64_t M, int64_t L, int D, sedd_stream_t stream);
+
+/* NO COUNTERPART IN THE REFERENCE — for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): sedd_ln_modulate_bwd followed by
+ * sedd_ln_modulate_bwd_reduce in one call, with the [3, nchunk, D] partial-sum workspace in a file-scope device array
+ * of the library (16 MiB per GPU, held until the process ends) instead of caller memory.  Same arguments and results as
+ * that pair (dw [D] +=; dshift / dscale [B, .] written with row stride dmod_stride, either may be NULL).  Limit:
+ * 3 * sedd_ln_bwd_chunks(M, L) * D <= SEDD_LN_BWD_NOALLOC_MAX_FLOATS, otherwise SEDD_ERR_UNSUPPORTED_SHAPE and nothing
+ * is launched (e.g. D = 768: up to 1820 chunks = 116480 rows of 64).  Calls no hipMalloc / hipFree.  All calls on one
+ * GPU share that GPU's array: calls that may run concurrently on one GPU (different streams) race — serialise them. */
+#define SEDD_LN_BWD_NOALLOC_MAX_FLOATS (4 * 1024 * 1024)
+int sedd_ln_modulate_bwd_noalloc(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                                 int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
+                                 const float* dx_add, float* dw, float* dshift, float* dscale, int64_t dmod_stride,
+                                 int64_t M, int64_t L, int D, sedd_stream_t stream);
 
 /* bias_dropout_add_scale (fused_add_dropout_scale.py:13-48), bias == None at every reference call site:
  * out = residual + gate_b * (a * keep / (1-p)).  residual/out fp32 [M,D], a in `a_dtype`, gate rows as in
@@ -264,10 +278,11 @@ int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
  * One pass over the flat fp32 parameter buffer: gradient clip coefficient (losses.py:65-66) -> AdamW
  * (losses.py:39-41; torch.optim.AdamW) -> EMA shadow update (model/ema.py:32-52) -> bf16 compute copy.
  * clip_coef: device scalar fp32 (min(1, max_norm/(norm+1e-6))), grad_scale multiplies g first (1/world etc.).
- * ema/p_bf16 may be NULL.  step is 1-based. */
+ * ema/p_bf16 may be NULL.  step is 1-based.  decoupled != 0: AdamW (p *= 1 - lr*weight_decay); 0: torch.optim.Adam's
+ * L2 form, g += weight_decay * p before the moments (losses.py:36-38 vs :39-41). */
 int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                         const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, float ema_decay, int64_t n, sedd_stream_t stream);
+                        float weight_decay, int decoupled, int step, float ema_decay, int64_t n, sedd_stream_t stream);
 /* out[0] = sum_r w[r / L] * x[r]  (losses.py:29: (dsigma[:, None] * loss).mean() with w_b = dsigma_b / M).
  * fp32, deterministic two-stage; ws fp32 [1024] caller workspace. */
 int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L, float* ws, float* out,
@@ -275,7 +290,8 @@ int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L
 /* model/ema.py:44-52 stand-alone: shadow -= one_minus_decay * (shadow - p), fp32, n elements. */
 int sedd_ema_update(float* shadow, const float* p, float one_minus_decay, int64_t n, sedd_stream_t stream);
 /* out[0] = sum_i g[i]^2 (fp32, deterministic two-stage); ws fp32 [1024] caller workspace.
- * Then, when max_norm > 0: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)). */
+ * Then, when max_norm >= 0: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)) (max_norm == 0 zeroes the
+ * gradients, as clip_grad_norm_ does); max_norm < 0: no clipping, out[1] is left untouched. */
 int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float max_norm, float* ws, float* out,
                     sedd_stream_t stream);
 

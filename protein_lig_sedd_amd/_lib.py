@@ -36,6 +36,7 @@ SIGNATURES = {
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_gate": "pipppilppppp" + "pp" + "flf" + "pp" + "llip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
+    "sedd_ln_modulate_bwd_noalloc": "pipppilpppp" + "pppl" + "llip",
     "sedd_gate_residual_fwd": "ppipilpflfpllip",
     "sedd_gate_residual_bwd": "ppipilpflfppillip",
     "sedd_gate_residual_bwd_reduce": "pplp" + "llip",
@@ -57,7 +58,7 @@ SIGNATURES = {
     "sedd_gemm_nn_dgelu": "plplpliipplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",
-    "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "i" + "f" + "lp",
+    "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
     "sedd_sumsq_clip": "plffppp",
     "sedd_ema_update": "ppflp",
     "sedd_batch_weighted_sum": "ppllppp",

@@ -367,24 +367,61 @@ extern "C" int sedd_ln_modulate_bwd_gate(const void* dy, int dy_dtype, const flo
                                 dx_add, ws, M, L, D, &ga, stream);
 }
 
-// out_k[b, j] = sum over the chunks of batch b of plane k;  planes in atomic_mask are instead summed over b as well,
-// into a [D] vector (atomic +=)
+// out_k[b, j] = sum over the chunks of batch b of plane k (blocks [0, nxb * B));  planes in vec_mask are instead summed
+// over ALL chunks into a [D] vector (+=) by the trailing "fold" blocks: 64 columns per block, 16 row groups of 16 column
+// quads each walk the chunks with stride 16 and meet in LDS in a fixed order — one writer per column, no atomics, so
+// the bias / LayerNorm-weight gradients come out bit-identical from run to run.
 __global__ void __launch_bounds__(TPB) chunk_reduce_kernel(const float* __restrict__ ws, int nplanes,
                                                            float* __restrict__ o0, float* __restrict__ o1,
-                                                           float* __restrict__ o2, int64_t ostride, int atomic_mask,
-                                                           int64_t nchunk, int64_t cpb, int D) {
-    const int j = blockIdx.x * TPB + threadIdx.x;
-    const int64_t b = blockIdx.y;
-    if (j >= D) return;
-    float s[3] = {0.f, 0.f, 0.f};
-    for (int64_t c = 0; c < cpb; ++c)
-        for (int k = 0; k < nplanes; ++k) s[k] += ws[((int64_t)k * nchunk + b * cpb + c) * D + j];
+                                                           float* __restrict__ o2, int64_t ostride, int vec_mask,
+                                                           int64_t nchunk, int64_t cpb, int D, int nxb, int64_t B) {
     float* outs[3] = {o0, o1, o2};
-    for (int k = 0; k < nplanes; ++k) {
-        if (!outs[k]) continue;
-        if ((atomic_mask >> k) & 1) atomicAdd(outs[k] + j, s[k]);  // [D] vector summed over the batch as well
-        else outs[k][b * ostride + j] = s[k];
+    const int64_t nperb = (int64_t)nxb * B;
+    if ((int64_t)blockIdx.x < nperb) {
+        const int j = (int)(blockIdx.x % nxb) * TPB + threadIdx.x;
+        const int64_t b = blockIdx.x / nxb;
+        if (j >= D) return;
+        for (int k = 0; k < nplanes; ++k) {
+            if (!outs[k] || ((vec_mask >> k) & 1)) continue;
+            float s = 0.f;
+            for (int64_t c = 0; c < cpb; ++c) s += ws[((int64_t)k * nchunk + b * cpb + c) * D + j];
+            outs[k][b * ostride + j] = s;
+        }
+        return;
     }
+    __shared__ float4 red[16][16];
+    const int col = (int)(blockIdx.x - nperb) * 64 + (threadIdx.x & 15) * 4, rg = threadIdx.x >> 4;
+    for (int k = 0; k < nplanes; ++k) {
+        if (!outs[k] || !((vec_mask >> k) & 1)) continue;
+        float4 a = f4(0.f);
+        if (col < D)
+            for (int64_t c = rg; c < nchunk; c += 16) {
+                const float4 v = load4<float>(ws + ((int64_t)k * nchunk + c) * D + col);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        red[rg][threadIdx.x & 15] = a;
+        __syncthreads();
+        if (threadIdx.x < 16 && col < D) {
+            float4 t = red[0][threadIdx.x];
+            for (int r = 1; r < 16; ++r) {
+                const float4 v = red[r][threadIdx.x];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float* o = outs[k] + col;  // (scalar accesses: the gradient vector need not be 16-byte aligned)
+            o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+        }
+        __syncthreads();
+    }
+}
+static void launch_chunk_reduce(const float* ws, int nplanes, float* o0, float* o1, float* o2, int64_t ostride,
+                                int vec_mask, int64_t nchunk, int64_t B, int D, hipStream_t st) {
+    const int nxb = (D + TPB - 1) / TPB;
+    bool vec = false;
+    float* outs[3] = {o0, o1, o2};
+    for (int k = 0; k < nplanes; ++k) vec = vec || (outs[k] && ((vec_mask >> k) & 1));
+    const unsigned nblk = (unsigned)(nxb * B + (vec ? (D + 63) / 64 : 0));
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3(nblk), dim3(TPB), 0, st, ws, nplanes, o0, o1, o2, ostride, vec_mask,
+                       nchunk, nchunk / B, D, nxb, B);
 }
 
 extern "C" int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* dshift, float* dscale,
@@ -393,10 +430,63 @@ extern "C" int sedd_ln_modulate_bwd_reduce(const float* ws, float* dw, float* ds
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(ws, "ln_modulate_bwd_reduce: ws is null");
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L), B = M / L;
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((D + TPB - 1) / TPB, (unsigned)B), dim3(TPB), 0, (hipStream_t)stream,
-                       ws, 3, dw, dshift, dscale, dmod_stride, 1, nchunk, nchunk / B, D);
+    SEDD_CHECK_ARG(D % 4 == 0, "ln_modulate_bwd_reduce: D %% 4 != 0");
+    launch_chunk_reduce(ws, 3, dw, dshift, dscale, dmod_stride, 1, nchunk, B, D, (hipStream_t)stream);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
+}
+
+// ---------------------------------------------------------------------------------- entry point that allocates nothing
+// sedd_ln_modulate_bwd + sedd_ln_modulate_bwd_reduce in one call, with the [3, nchunk, D] partial-sum workspace in a
+// file-scope device array instead of caller memory: for callers that cannot allocate (HIP graph capture, serving loops,
+// harnesses that forbid hipMalloc).  Each GPU holds its own copy of the array at its own address; the address is looked
+// up once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels.
+#define SEDD_LN_BWD_SCRATCH_FLOATS SEDD_LN_BWD_NOALLOC_MAX_FLOATS /* 16 MiB per GPU, held until the process ends */
+#define SEDD_MAX_DEVICES 64
+static __device__ __align__(256) float ln_bwd_scratch[SEDD_LN_BWD_SCRATCH_FLOATS];
+static float* volatile ln_bwd_scratch_ptr[SEDD_MAX_DEVICES];  // per device; written once (idempotent value)
+
+static int ln_bwd_scratch_for_current_device(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SEDD_MAX_DEVICES) {
+        sedd_set_error("ln_modulate_bwd_noalloc: no current device (or device index %d >= %d)", dev, SEDD_MAX_DEVICES);
+        return SEDD_ERR_LAUNCH;
+    }
+    float* p = ln_bwd_scratch_ptr[dev];
+    if (!p) {  // first call on this device (racing first calls resolve the same address)
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(ln_bwd_scratch));
+        if (e != hipSuccess || !p) {
+            sedd_set_error("ln_modulate_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return SEDD_ERR_LAUNCH;
+        }
+        ln_bwd_scratch_ptr[dev] = p;
+    }
+    *out = p;
+    return SEDD_OK;
+}
+
+extern "C" int sedd_ln_modulate_bwd_noalloc(const void* dy, int dy_dtype, const float* x, const float* w,
+                                            const void* scale, int mod_dtype, int64_t mod_stride, const float* mean,
+                                            const float* rstd, float* dx, const float* dx_add, float* dw, float* dshift,
+                                            float* dscale, int64_t dmod_stride, int64_t M, int64_t L, int D,
+                                            sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && M % L == 0 && D > 0, "ln_modulate_bwd_noalloc: bad sizes M=%ld L=%ld D=%d", (long)M,
+                   (long)L, D);
+    if (M == 0) return SEDD_OK;
+    const int64_t need = 3 * sedd_ln_bwd_chunks(M, L) * (int64_t)D;
+    if (need > (int64_t)SEDD_LN_BWD_SCRATCH_FLOATS) {
+        sedd_set_error("ln_modulate_bwd_noalloc: M=%ld L=%ld D=%d needs %ld workspace floats, the static scratch holds %ld "
+                       "(16 MiB): use sedd_ln_modulate_bwd with a caller workspace", (long)M, (long)L, D, (long)need,
+                       (long)SEDD_LN_BWD_SCRATCH_FLOATS);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    float* ws = nullptr;
+    int rc = ln_bwd_scratch_for_current_device(&ws);
+    if (rc != SEDD_OK) return rc;
+    rc = ln_modulate_bwd_impl("ln_modulate_bwd_noalloc", dy, dy_dtype, x, w, scale, mod_dtype, mod_stride, mean, rstd, dx,
+                              dx_add, ws, M, L, D, nullptr, stream);
+    if (rc != SEDD_OK) return rc;
+    return sedd_ln_modulate_bwd_reduce(ws, dw, dshift, dscale, dmod_stride, M, L, D, stream);
 }
 
 // ====================================================================================== gated residual fwd
@@ -645,8 +735,9 @@ extern "C" int sedd_gate_residual_bwd_reduce(const float* ws, float* dgate, int6
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(ws && dgate, "gate_residual_bwd_reduce: null pointer");
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L), B = M / L;
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((D + TPB - 1) / TPB, (unsigned)B), dim3(TPB), 0, (hipStream_t)stream,
-                       ws, dbias ? 2 : 1, dgate, dbias, (float*)nullptr, dmod_stride, dbias ? 2 : 0, nchunk, nchunk / B, D);
+    SEDD_CHECK_ARG(D % 4 == 0, "gate_residual_bwd_reduce: D %% 4 != 0");
+    launch_chunk_reduce(ws, dbias ? 2 : 1, dgate, dbias, (float*)nullptr, dmod_stride, dbias ? 2 : 0, nchunk, B, D,
+                        (hipStream_t)stream);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ ema, bf16_t* __restrict__ pb,
                                                         const float* __restrict__ clip, float gscale, float decay_mul,
-                                                        float beta1, float beta2, float eps, float step_size,
+                                                        float l2, float beta1, float beta2, float eps, float step_size,
                                                         float inv_bc2_sqrt, float one_m_ema, int64_t n) {
     const float cs = (clip ? clip[0] : 1.0f) * gscale;
     const int64_t nv = n / 4;
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
         float* P = &pp.x; const float* G = &gg.x; float* Mm = &mm.x; float* Vv = &vv.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gk = G[k] * cs;
+            const float gk = G[k] * cs + l2 * P[k];  // l2 != 0: torch.optim.Adam's weight decay (decay_mul is then 1)
             P[k] *= decay_mul;
             Mm[k] = Mm[k] * beta1 + gk * (1.0f - beta1);
             Vv[k] = Vv[k] * beta2 + gk * gk * (1.0f - beta2);
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
 
 extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                                    const float* clip_coef, float grad_scale, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, int step, float ema_decay, int64_t n,
+                                   float eps, float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
                                    sedd_stream_t stream) {
     SEDD_CHECK_ARG(n >= 0 && step >= 1, "adamw_ema_step: bad n=%ld step=%d", (long)n, step);
     if (n % 4 != 0) {
@@ -60,9 +60,10 @@ extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v,
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    const float decay_mul = decoupled ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
+    const float l2 = decoupled ? 0.0f : weight_decay;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(sedd_grid_for(n / 4, TPB, 256 * 16)), dim3(TPB), 0, (hipStream_t)stream,
-                       p, g, m, v, ema, (bf16_t*)p_bf16, clip_coef, grad_scale, decay_mul, beta1, beta2, eps, step_size,
+                       p, g, m, v, ema, (bf16_t*)p_bf16, clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size,
                        inv_bc2_sqrt, 1.0f - ema_decay, n);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
@@ -110,7 +111,9 @@ __global__ void __launch_bounds__(TPB) sumsq_stage2(const float* __restrict__ ws
     if (threadIdx.x == 0) {
         const float t = (red[0] + red[1]) + (red[2] + red[3]);
         out[0] = t;
-        if (max_norm > 0.f) out[1] = fminf(1.0f, max_norm / (sqrtf(t) * gscale + 1e-6f));
+        // clip_grad_norm_(max_norm): max_norm == 0 zeroes the gradients (losses.py:65-66 clips whenever grad_clip >= 0);
+        // a negative max_norm means "no clipping" and leaves out[1] alone
+        if (max_norm >= 0.f) out[1] = fminf(1.0f, max_norm / (sqrtf(t) * gscale + 1e-6f));
     }
 }
 
@@ -144,7 +147,7 @@ extern "C" int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M
     const int nb = M == 0 ? 1 : sedd_grid_for(M, TPB * 4, SUMSQ_MAX_BLOCKS);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wsum_stage1, dim3(nb), dim3(TPB), 0, st, x, w, M, L, ws);
-    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TPB), 0, st, ws, nb, 1.0f, 0.0f, out);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TPB), 0, st, ws, nb, 1.0f, -1.0f, out);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

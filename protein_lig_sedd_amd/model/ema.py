@@ -5,6 +5,12 @@ import torch
 from .. import ops
 
 
+def _drop_weight_cache(param):
+    """forget the cached compute-dtype copy of a parameter whose values were just overwritten in place."""
+    if getattr(param, "_sedd_wc", None) is not None:
+        param._sedd_wc = None
+
+
 class ExponentialMovingAverage:
     def __init__(self, parameters, decay, use_num_updates=True):
         if decay < 0.0 or decay > 1.0:
@@ -37,17 +43,24 @@ class ExponentialMovingAverage:
                     raise RuntimeError("ExponentialMovingAverage.update needs CUDA(HIP) parameters: no CPU fallback")
 
     def copy_to(self, parameters):
+        """ema.py:54-66.  The copy goes through `param.copy_` (not `param.data.copy_`): it bumps the parameter's
+        version counter, which is what the compute-dtype weight cache of model/layers.py is keyed on — a forward after
+        copy_to must see the EMA weights in every Linear, not a stale bf16 copy of the training weights."""
         parameters = [p for p in parameters if p.requires_grad]
-        for s_param, param in zip(self.shadow_params, parameters):
-            if param.requires_grad:
-                param.data.copy_(s_param.data)
+        with torch.no_grad():
+            for s_param, param in zip(self.shadow_params, parameters):
+                param.copy_(s_param)
+                _drop_weight_cache(param)
 
     def store(self, parameters):
-        self.collected_params = [param.clone() for param in parameters]
+        self.collected_params = [param.detach().clone() for param in parameters]
 
     def restore(self, parameters):
-        for c_param, param in zip(self.collected_params, parameters):
-            param.data.copy_(c_param.data)
+        """ema.py:76-91 (same version-bumping copy as copy_to)."""
+        with torch.no_grad():
+            for c_param, param in zip(self.collected_params, parameters):
+                param.copy_(c_param)
+                _drop_weight_cache(param)
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
@@ -55,4 +68,13 @@ class ExponentialMovingAverage:
     def load_state_dict(self, state_dict):
         self.decay = state_dict['decay']
         self.num_updates = state_dict['num_updates']
-        self.shadow_params = state_dict['shadow_params']
+        new = state_dict['shadow_params']
+        # same values as the reference's plain assignment (ema.py:96-99), but written INTO the existing shadow tensors
+        # when they line up: under the flat-buffer trainer they are views of one buffer that the fused kernel updates
+        if len(new) == len(self.shadow_params) and all(a.shape == b.shape for a, b in zip(new, self.shadow_params)):
+            with torch.no_grad():
+                for dst, src in zip(self.shadow_params, new):
+                    if dst is not src:
+                        dst.copy_(src)
+        else:
+            self.shadow_params = new

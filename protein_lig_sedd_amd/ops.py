@@ -328,7 +328,11 @@ class DropSeed:
     def __init__(self, p, seed=None):
         if seed is None:
             DropSeed._counter += 1
-            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + DropSeed._counter * 0xD1B54A32D192ED03) & 0x7FFFFFFFFFFFFFFF
+            # the rank is mixed in: data-parallel ranks are seeded identically (same initial weights) but must draw
+            # their own dropout masks, as the reference's DDP ranks do from their own device generators
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + DropSeed._counter * 0xD1B54A32D192ED03
+                    + rank * 0xA24BAED4963EE407) & 0x7FFFFFFFFFFFFFFF
         self.seed, self.p = int(seed), float(p)
 
 
@@ -665,10 +669,13 @@ def sumsq_clip(g, gscale=1.0, max_norm=0.0, ws=None, out=None):
     return out
 
 
-def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, step, ema_decay):
+def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, step, ema_decay,
+                   decoupled=True):
+    """decoupled=True: AdamW (p *= 1 - lr*wd); False: torch.optim.Adam's L2 form (g += wd*p before the moments)."""
     check(lib().sedd_adamw_ema_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(p_bf16), _p(clip_coef), float(grad_scale),
-                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                    float(ema_decay), p.numel(), _stream()), "sedd_adamw_ema_step")
+                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                    1 if decoupled else 0, int(step), float(ema_decay), p.numel(), _stream()),
+          "sedd_adamw_ema_step")
 
 
 def ema_update_(shadow, p, one_minus_decay):

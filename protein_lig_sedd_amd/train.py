@@ -30,7 +30,13 @@ class FlatState:
     """Flat parameter / gradient / optimiser-state buffers for a list of parameters."""
 
     def __init__(self, params, compute_dtype=torch.bfloat16, with_ema=True):
+        params = list(params)
         self.params = [p for p in params if p.requires_grad]
+        # position of every trainable parameter in the full parameter list: torch optimizers index their state by it
+        # (frozen parameters keep their slot and simply have no state), so reference checkpoints of task-frozen runs map
+        # onto the right tensors
+        self.index = [i for i, p in enumerate(params) if p.requires_grad]
+        self.n_all = len(params)
         dev = self.params[0].device
         self.offsets, n = [], 0
         for p in self.params:
@@ -75,8 +81,12 @@ def init_distributed():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("SEDD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        if backend != "nccl":  # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (gloo moves the bytes)
-            local = local % torch.cuda.device_count()
+        if backend != "nccl":
+            # gloo stages device tensors through the host from its own threads; on this stack every such all-reduce of
+            # a buffer that the launch stream is still writing hung (round-1 rehearsals, also with plain torch ops and
+            # none of this package's kernels).  The collectives of this path are RCCL's; gloo is for CPU tensors.
+            raise RuntimeError(f"init_distributed: backend {backend!r} cannot carry GPU tensors here — use 'nccl' "
+                               "(RCCL); gloo is supported for CPU tensors only")
         torch.cuda.set_device(local)
     if (world > 1 or os.environ.get("SEDD_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -92,11 +102,21 @@ class SEDDTrainer:
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
-                 process_group=None, overlap=True, lr_schedule=None):
+                 process_group=None, overlap=True, lr_schedule=None, ema=None):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
         self.warmup, self.grad_clip = g("warmup", 0), g("grad_clip", 1.0)
+        # losses.py:35-46: 'Adam' puts weight_decay into the gradient (L2), 'AdamW' decouples it; the fused kernel takes
+        # either form.  Anything else is the reference's NotImplementedError.
+        self.optimizer_name = g("optimizer", "AdamW")
+        if self.optimizer_name not in ("Adam", "AdamW"):
+            raise NotImplementedError(f'Optimizer {self.optimizer_name} not supported yet!')
+        self.decoupled_wd = self.optimizer_name == "AdamW"
+        if g("accum", 1) not in (None, 1):
+            raise NotImplementedError("gradient accumulation (training.accum != 1) is not supported by the fused step; "
+                                      "the reference's step_fn resets its counter every call (losses.py:84) and only "
+                                      "works for accum == 1 either")
         self.model, self.noise, self.graph = model, noise, graph
         # optional step -> lr callable (e.g. lr_scheduler.warmup_cosine_lr of the cross-attention trainer,
         # run_train_protlig_cross_att.py); default = losses.py:58-62 linear warm-up
@@ -106,7 +126,12 @@ class SEDDTrainer:
         cdt = getattr(model, "compute_dtype", torch.float32)
         self.flat = FlatState(list(model.parameters()), cdt, with_ema=True)
         self.ema_decay = ema_decay
-        self.ema = ExponentialMovingAverage([], ema_decay)
+        if ema is None:
+            self.ema = ExponentialMovingAverage([], ema_decay)
+        else:  # adopt an EMA object the caller already holds (losses.get_step_fn): its shadow moves into the flat buffer
+            self.ema = ema
+            for dst, src in zip(self.flat.ema_params(), ema.shadow_params):
+                dst.copy_(src)
         self.ema.shadow_params = self.flat.ema_params()
         self.loss_fn = get_loss_fn(noise, graph, train=True, sampling_eps=sampling_eps)
         self.step_count = 0
@@ -123,6 +148,7 @@ class SEDDTrainer:
         # costs less than that and nothing at all at N = 1.
         self.overlap = overlap and self.dp and os.environ.get("SEDD_DP_OVERLAP", "0") == "1"
         self._pending = []
+        self._ar_events = []
         self._buckets = self._make_buckets()
         if self.dp:
             self.broadcast_parameters()
@@ -175,8 +201,15 @@ class SEDDTrainer:
         self.model.train()
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
         loss.backward()
+        self.apply_gradients()
+        return loss.detach()
+
+    def apply_gradients(self, step=None):
+        """all-reduce -> clip -> Adam(W) -> EMA on whatever the flat gradient buffer holds (losses.py:52-69 + :102).
+        step: the 1-based optimiser step this is (default: the next one)."""
+        fl = self.flat
         self._reduce_gradients()
-        self.step_count += 1
+        self.step_count = self.step_count + 1 if step is None else int(step)
         gscale = 1.0 / self.world
         clip = None
         if self.grad_clip is not None and self.grad_clip >= 0:
@@ -185,9 +218,8 @@ class SEDDTrainer:
         self.ema.num_updates += 1
         decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
         ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, self.current_lr(self.step_count),
-                           self.beta1, self.beta2, self.eps, self.wd, self.step_count, decay)
+                           self.beta1, self.beta2, self.eps, self.wd, self.step_count, decay, self.decoupled_wd)
         fl.refresh_compute_weights()
-        return loss.detach()
 
     def _reduce_gradients(self):
         """Finish the gradient all-reduce (SUM; the 1/world averaging is folded into the optimiser kernel's grad_scale):
@@ -203,7 +235,25 @@ class SEDDTrainer:
                 w.wait()
             self._pending = []
         else:
+            timed = fl.g.is_cuda and len(self._ar_events) < 256
+            if timed:  # the launch stream waits for RCCL's stream here, so the pair brackets the collective
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(fl.g, group=self.pg)
+            if timed:
+                e1.record()
+                self._ar_events.append((e0, e1))
+
+    def reset_allreduce_timing(self):
+        self._ar_events = []
+
+    def allreduce_ms_per_step(self):
+        """mean time of the (non-overlapped) gradient all-reduce since the last reset, from HIP events on the launch
+        stream; None when no collective ran (single process) or in the overlapped form."""
+        if not self._ar_events:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._ar_events) / len(self._ar_events)
 
     def _leftover_ranges(self, done):
         cov = sorted(done)
@@ -233,13 +283,21 @@ class SEDDTrainer:
         """torch.optim.Adam/AdamW `state_dict()` layout (what utils/utils.py:88 stores and :80 loads): per-parameter
         `step` / `exp_avg` / `exp_avg_sq` in `model.parameters()` order, views of the flat moment buffers."""
         fl = self.flat
-        step = torch.tensor(float(self.step_count))
-        state = {i: {"step": step.clone(), "exp_avg": fl.view(fl.m, i), "exp_avg_sq": fl.view(fl.v, i)}
-                 for i in range(len(fl.params))} if self.step_count > 0 else {}
+        step = torch.tensor(float(self._adam_steps()))
+        # keys = positions in model.parameters() (frozen parameters own a slot but no state, as in torch)
+        state = {fl.index[i]: {"step": step.clone(), "exp_avg": fl.view(fl.m, i), "exp_avg_sq": fl.view(fl.v, i)}
+                 for i in range(len(fl.params))} if self._adam_steps() > 0 else {}
         group = {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": self.wd,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-                 "fused": None, "params": list(range(len(fl.params)))}
+                 "fused": None, "params": list(range(fl.n_all))}
         return {"state": state, "param_groups": [group]}
+
+    def _adam_steps(self):
+        """the optimiser's own step counter (what torch stores per parameter as `step`)."""
+        return self.step_count
+
+    def _set_adam_steps(self, n):
+        pass
 
     def load_optimizer_state_dict(self, sd):
         """accepts the reference's torch-optimizer layout (extra trailing parameters, e.g. the noise schedule's dummy
@@ -248,7 +306,7 @@ class SEDDTrainer:
         if "state" in sd:
             steps = []
             for i in range(len(fl.params)):
-                ent = sd["state"].get(i)
+                ent = sd["state"].get(fl.index[i])
                 if ent is None:
                     fl.view(fl.m, i).zero_()
                     fl.view(fl.v, i).zero_()
@@ -272,6 +330,7 @@ class SEDDTrainer:
         self.model.load_state_dict(model_sd)
         opt_step = self.load_optimizer_state_dict(sd["optimizer"])
         self.step_count = int(sd.get("step", opt_step))
+        self._set_adam_steps(opt_step)
         for dst, src in zip(self.flat.ema_params(), sd["ema"]["shadow_params"]):
             dst.copy_(src)
         self.ema.num_updates = sd["ema"]["num_updates"]
@@ -354,6 +413,14 @@ class CrossAttTrainer(SEDDTrainer):
         self.sampling_eps = sampling_eps
         self.opt_steps = 0  # Adam's own step counter (advances twice per iteration with double_step)
 
+    def _adam_steps(self):
+        return self.opt_steps
+
+    def _set_adam_steps(self, n):
+        """resume: Adam's bias correction continues from the optimiser's stored step (2x the iteration count under
+        double_step), not from 0."""
+        self.opt_steps = int(n)
+
     @staticmethod
     def freeze_model(model, freeze_what):
         for name, param in model.named_parameters():
@@ -415,11 +482,11 @@ class CrossAttTrainer(SEDDTrainer):
         decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
         self.opt_steps += 1
         ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
-                           self.wd, self.opt_steps, decay)
+                           self.wd, self.opt_steps, decay, self.decoupled_wd)
         if self.double_step:  # Q2: the same clipped gradients once more; EMA already took the first step's weights
             self.opt_steps += 1
             ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
-                               self.eps, self.wd, self.opt_steps, 1.0)
+                               self.eps, self.wd, self.opt_steps, 1.0, self.decoupled_wd)
         fl.refresh_compute_weights()
         if task == "joint":
             return loss.detach(), out[1].mean().detach(), out[2].mean().detach()

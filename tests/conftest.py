@@ -12,8 +12,28 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_DP_CHILD = {"proc": None, "path": None}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tests/test_gpu_dp_nccl.py needs a FRESH process for its 1-rank RCCL group.  A process that has initialised the
+    # GPU must not start programs on this pool, so the child is started here, before any test touches the device
+    # (torch.cuda.device_count() does not initialise it), and the test collects the result later.
+    mark = config.getoption("-m", default="") or ""
+    if "gpu" in mark and "not gpu" not in mark and torch.cuda.device_count() > 0 and not os.environ.get("SEDD_NO_DP_CHILD"):
+        import subprocess
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(prefix="sedd_dp_"), "result.json")
+        log = open(path + ".log", "w")
+        _DP_CHILD["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_nccl_child.py"), path],
+                                             stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+        _DP_CHILD["path"] = path
+
+
+@pytest.fixture(scope="session")
+def dp_nccl_child():
+    return _DP_CHILD["proc"], _DP_CHILD["path"]
 
 
 class Golden:

@@ -1,0 +1,88 @@
+"""Child process of tests/test_gpu_dp_nccl.py (started by conftest.py BEFORE the pytest process touches the GPU).
+
+One rank, backend "nccl" (= RCCL): the data-parallel form of SEDDTrainer.train_step — parameter broadcast, gradient
+all-reduce on RCCL's stream (one call after backward, and the per-block overlapped buckets of SEDD_DP_OVERLAP=1),
+stream ordering against the optimiser kernel — must leave exactly the bits the single-process step leaves
+(reference: training/run_train_ddp_protlig_transf.py:160-165 init, :197 DDP wrap, :285 loss all-reduce).
+Batch 2 keeps every fp32 atomic accumulation of the backward at <= 2 addends per address, i.e. order-independent, so
+the comparison can be bitwise.  Writes one JSON object to the path given as argv[1]."""
+import json
+import os
+import sys
+import traceback
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out_path):
+    res = {"ok": False}
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=os.environ.get("SEDD_TEST_PORT", "29731"), SEDD_DP_FORCE="1")
+        os.environ.pop("SEDD_DIST_BACKEND", None)
+        from protein_lig_sedd_amd import graph_lib, noise_lib
+        from protein_lig_sedd_amd.model.transformer import _SEDD
+        from protein_lig_sedd_amd.train import SEDDTrainer, init_distributed
+        rank, local, world = init_distributed()
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        dev = torch.device("cuda", local)
+        ns = types.SimpleNamespace
+        cfg = ns(tokens=25, graph=ns(type="absorb"),
+                 model=ns(hidden_size=128, cond_dim=64, n_heads=2, n_blocks=3, dropout=0.0, scale_by_sigma=True))
+        g = torch.Generator().manual_seed(7)
+        B, L = 2, 128
+        x0 = [torch.randint(0, 25, (B, L), generator=g).to(dev) for _ in range(3)]
+        t = [(torch.rand(B, generator=g) * 0.9 + 0.05).to(dev) for _ in range(3)]
+        u = [torch.rand(B, L, generator=g).to(dev) for _ in range(3)]
+
+        def run(force, overlap, cdt):
+            os.environ["SEDD_DP_FORCE"] = "1" if force else "0"
+            os.environ["SEDD_DP_OVERLAP"] = "1" if overlap else "0"
+            torch.manual_seed(3)
+            model = _SEDD(cfg, compute_dtype=cdt).to(dev)
+            with torch.no_grad():  # the reference zero-initialises adaLN / output weights: make every path live
+                for p in model.parameters():
+                    if p.dim() >= 2:
+                        p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev) * 0.05)
+            tr = SEDDTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(dev), graph_lib.Absorbing(25),
+                             dict(lr=1e-3, warmup=0, grad_clip=1.0, weight_decay=0.01), world_size=1)
+            assert tr.dp == force and tr.overlap == (force and overlap)
+            losses = [float(tr.train_step(x0[i], t=t[i], u=u[i])) for i in range(3)]
+            avg = float(tr.reduce_loss(torch.tensor(losses[-1], device=dev)))
+            torch.cuda.synchronize()
+            return losses, tr.flat.p.clone(), tr.flat.ema.clone(), tr.flat.m.clone(), avg
+
+        res["cases"] = {}
+        ok = True
+        for cdt in (torch.float32, torch.bfloat16):
+            base = run(False, False, cdt)
+            for name, overlap in (("allreduce_after_backward", False), ("per_block_overlap", True)):
+                got = run(True, overlap, cdt)
+                same = (got[0] == base[0] and torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
+                        and torch.equal(got[3], base[3]) and got[4] == base[0][-1])
+                res["cases"][f"{name}/{str(cdt).split('.')[-1]}"] = {
+                    "bit_identical": bool(same), "losses": got[0], "base_losses": base[0],
+                    "max_abs_param_diff": float((got[1] - base[1]).abs().max())}
+                ok = ok and same
+        # gloo must be refused on device tensors (it hangs on this image; see train.init_distributed)
+        dist.barrier()
+        dist.destroy_process_group()
+        os.environ.update(SEDD_DIST_BACKEND="gloo", SEDD_DP_FORCE="1")
+        try:
+            init_distributed()
+            res["gloo_refused"] = False
+        except RuntimeError as e:
+            res["gloo_refused"] = "gloo" in str(e)
+        res["ok"] = bool(ok and res["gloo_refused"])
+    except Exception:
+        res["error"] = traceback.format_exc()
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -184,3 +184,59 @@ def test_cross_trainer_task_freezing():
     after = model.state_dict()
     changed = {k for k in before if not torch.equal(before[k], after[k])}
     assert changed and all("lig" not in k for k in changed)
+
+
+def test_cfg3_dimensions_match_the_oracle():
+    """BASELINE configs[2] at its own dimensions — D 1024, 32 heads of 32, cond 128, protein L 512 (V 37) + ligand L 128
+    (V 2365), batch 4 (configs/config_prot_only.yaml:6-11, config.yaml:25, data/tokenize.py:14,25) — with one block per
+    track to keep the CPU oracle quick: `joint` logits, the as-written Q3 loss and weight gradients, and `protein_only`
+    logits, against oracle.cross_joint / cross_single_track (transformers_protlig_cross.py:279-320, 455-517).  The
+    batch-axis MHA (quirk Q1) here is 512 (or 128) "batches" x 32 heads attending over a length-4 "sequence": a launch
+    shape none of the D 64 goldens reach.  fp32 compute as the reference (autocast(float32), :401/:478): 1e-4."""
+    from oracle import sedd_cpu as O
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd import graph_lib
+    D, H, C, nb, B, Lp, Ll = 1024, 32, 128, 1, 4, 512, 128
+    sd = seeded_state_dict(cross_shapes(D, C, nb), seed=33, std=0.03)
+    model = ProteinLigandDiffusionModel(_cfg(D, H, C, nb)).to(DEV)
+    load_sd(model, sd)
+    gen = torch.Generator().manual_seed(33)
+    p0 = torch.randint(0, 33, (B, Lp), generator=gen)
+    l0 = torch.randint(0, 2362, (B, Ll), generator=gen)
+    t = torch.rand(B, generator=gen) * 0.9 + 0.05
+    on = O.make_noise("loglinear", eps=1e-3)
+    sigma, dsigma = on(t)
+    gp_cpu, gl_cpu = O.AbsorbingCPU(36), O.AbsorbingCPU(2364)
+    pt = gp_cpu.sample_transition(p0, sigma[:, None], torch.rand(B, Lp, generator=gen))
+    lt = gl_cpu.sample_transition(l0, sigma[:, None], torch.rand(B, Ll, generator=gen))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rp, rl = O.cross_joint(sdr, pt, lt, sigma, H, nb)
+    se_p = gp_cpu.score_entropy(rp, sigma[:, None], pt, p0)
+    se_l = gl_cpu.score_entropy(rl, sigma[:, None], lt, l0)
+    ref_loss = (dsigma[:, None] * ((se_p.mean() + se_l.mean()) / 2)).mean()   # Q3, run_train_protlig_cross_att.py:289-294
+    ref_loss.backward()
+    ptd, ltd, p0d, l0d, sg, dsg = (z.to(DEV) for z in (pt, lt, p0, l0, sigma, dsigma))
+    model.train()
+    lp, ll = model(protein_indices=ptd, ligand_indices=ltd, timesteps=sg, mode="joint")
+    assert lp.shape == (B, Lp, 37) and ll.shape == (B, Ll, 2365)
+    assert rel_err(lp, rp.detach()) < 1e-4 and rel_err(ll, rl.detach()) < 1e-4
+    assert_close(lp, rp.detach(), 1e-4, 2e-4, "joint protein logits")
+    assert_close(ll, rl.detach(), 1e-4, 2e-4, "joint ligand logits")
+    gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+    loss = (dsg[:, None] * ((gp.score_entropy(lp, sg[:, None], ptd, p0d).mean()
+                             + gl.score_entropy(ll, sg[:, None], ltd, l0d).mean()) / 2)).mean()
+    assert_close(loss, ref_loss.detach(), 1e-4, 0, "Q3 loss")
+    loss.backward()
+    named = dict(model.named_parameters())
+    for k in ("transformer.blocks_prot.0.attn_qkv.weight", "transformer.blocks_prot.0.attn.in_proj_weight",
+              "transformer.blocks_lig.0.cross_attn.cross_attn.in_proj_weight", "transformer.blocks_lig.0.mlp.2.weight",
+              "transformer.blocks_prot.0.adaLN_modulation.weight", "transformer.ligand_output.linear.weight",
+              "transformer.protein_embed.embedding.weight", "transformer.sigma_map.mlp.2.weight"):
+        err = rel_err(named[k].grad, sdr[k].grad)
+        assert err < 2e-4, f"{k}: relative gradient error {err:.3e}"
+    model.eval()
+    with torch.no_grad():
+        ref_po = O.cross_single_track(sd, pt, sigma, "protein", H, nb)
+        got_po = model(protein_indices=ptd, timesteps=sg, mode="protein_only")
+    assert rel_err(got_po, ref_po) < 1e-4
+    assert_close(got_po, ref_po, 1e-4, 2e-4, "protein_only logits")

@@ -1,0 +1,31 @@
+"""D1 on the one GPU a test box has: the N > 1 code path of SEDDTrainer over a 1-rank RCCL group (backend "nccl"),
+bit-identical to the single-process step, for the default (one all-reduce after backward) and the overlapped
+per-block form.  The work runs in a child process that conftest.py starts before this process initialises the GPU
+(tests/dp_nccl_child.py); this test only collects its verdict."""
+import json
+import os
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_step_is_bit_identical(dp_nccl_child):
+    proc, path = dp_nccl_child
+    if proc is None:
+        pytest.skip("child process was not started (no GPU visible at session start)")
+    t0 = time.time()
+    while proc.poll() is None and time.time() - t0 < 240:
+        time.sleep(0.5)
+    if proc.poll() is None:
+        proc.kill()
+        pytest.fail("1-rank RCCL child did not finish within 240 s")
+    assert os.path.exists(path), f"child exited with {proc.returncode} and left no result"
+    res = json.load(open(path))
+    assert "error" not in res, res.get("error")
+    for name, c in res["cases"].items():
+        assert c["bit_identical"], f"{name}: dp step differs from the single-process step: {c}"
+    assert len(res["cases"]) == 4
+    assert res["gloo_refused"], "init_distributed must refuse gloo for device tensors"
+    assert res["ok"]

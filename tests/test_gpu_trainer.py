@@ -5,7 +5,7 @@ import types
 import pytest
 import torch
 
-from conftest import assert_close
+from conftest import assert_close, rel_err
 from oracle.weights import seeded_state_dict
 from test_oracle_vs_golden import sedd_shapes
 
@@ -71,15 +71,17 @@ def test_bf16_training_reduces_loss():
 
 
 @pytest.mark.parametrize("cdt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
-def test_large_config_dims_match_the_oracle(cdt, tol):
-    """BASELINE configs[3] dimensions (D 1024, 16 heads of 64, cond 128, L 1024; 2 blocks, batch 2 to keep the CPU oracle
-    quick): loss and every weight gradient of one step against the oracle — exercises the wide LayerNorm / GEMM tile /
-    long-sequence attention paths that the cfg-2 goldens do not reach."""
+@pytest.mark.parametrize("dims", [(768, 12, 512), (1024, 16, 1024)], ids=["cfg2_small_D768_H12_L512", "cfg4_large_D1024_H16_L1024"])
+def test_baseline_config_dims_match_the_oracle(dims, cdt, tol):
+    """The dimensions of BASELINE configs[1] (SEDD small: D 768, 12 heads of 64, cond 128, L 512 — the bench workload) and
+    configs[3] (large: D 1024, 16 heads of 64, L 1024), with 2 blocks and batch 2 to keep the CPU oracle quick: loss and
+    weight gradients of one step against the oracle — the model-level check at the real hidden size / head count /
+    sequence length (GEMM tile shapes, rotary-in-epilogue QKV projection, long-sequence attention, wide LayerNorm)."""
     from oracle import sedd_cpu as O
     from protein_lig_sedd_amd import graph_lib, noise_lib
     from protein_lig_sedd_amd.losses import get_loss_fn
     from protein_lig_sedd_amd.model.transformer import _SEDD
-    D, H, C, nb, tokens, B, L = 1024, 16, 128, 2, 25, 2, 1024
+    (D, H, L), C, nb, tokens, B = dims, 128, 2, 25, 2
     torch.manual_seed(5)
     model = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
     sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=21)
@@ -89,14 +91,145 @@ def test_large_config_dims_match_the_oracle(cdt, tol):
     og, on = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
     xt = og.sample_transition(x0, on(t)[0][:, None], u)
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref_loss, _ = O.sedd_loss(sdr, og, on, x0, t, xt, H, nb)
+    ref_loss, ref_logits = O.sedd_loss(sdr, og, on, x0, t, xt, H, nb)
     ref_loss.backward()
     loss = get_loss_fn(noise, graph, train=True)(model, x0.to(DEV), t=t.to(DEV), perturbed_batch=xt.to(DEV))
     loss.backward()
     assert_close(loss, ref_loss.detach(), tol, 0, "loss")
+    with torch.no_grad():
+        logits = model(xt.to(DEV), on(t)[0].to(DEV))
+    assert rel_err(logits.float(), ref_logits.detach()) < tol, "logits"
     for k in ("blocks.0.attn_qkv.weight", "blocks.1.mlp.2.weight", "blocks.0.adaLN_modulation.weight",
               "blocks.1.norm2.weight", "output_layer.linear.weight", "vocab_embed.embedding.weight"):
         p = dict(model.named_parameters())[k]
         ref = sdr[k].grad
         err = float((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
         assert err < (2e-4 if cdt == torch.float32 else 5e-2), f"{k}: relative gradient error {err:.3e}"
+
+
+def _ref_style_state(model, noise, cfg):
+    """the reference's training state dict (run_train_ddp_protlig_transf.py:198-213) built with the drop-in factories."""
+    from itertools import chain
+    from protein_lig_sedd_amd import losses
+    from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.training.ema)
+    optimizer = losses.get_optimizer(cfg, chain(model.parameters(), noise.parameters()))
+    return dict(optimizer=optimizer, scaler=None, model=model, noise=noise, ema=ema, step=0)
+
+
+def test_g12_through_get_step_fn(golden, tmp_path):
+    """The reference's own driver shape — losses.get_optimizer / optimization_manager / get_step_fn over a `state` dict
+    (losses.py:35-117, run_train_ddp_protlig_transf.py:207-239) — reaches the fused flat-buffer step and reproduces the
+    4-step trajectory captured from the reference (g12): losses, state['step'], final weights, the caller's EMA object;
+    then the eval step_fn (EMA store / copy_to / restore) and a save / restore round trip in the reference's layout."""
+    from protein_lig_sedd_amd import graph_lib, losses, noise_lib
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import restore_checkpoint, save_checkpoint
+    g = golden("g12_train_trajectory")
+    D, H, C, nb, tokens = g["cfg"].tolist()
+    lr, b1, b2, eps, wd, warmup, clip, decay = g["hyper"].tolist()
+    ns = types.SimpleNamespace
+    cfg = _cfg(D, H, C, nb, tokens)
+    cfg.optim = ns(optimizer="AdamW", lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, warmup=warmup, grad_clip=clip)
+    cfg.training = ns(ema=decay, accum=1)
+    model = _SEDD(cfg, compute_dtype=torch.float32).to(DEV)
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=12)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    state = _ref_style_state(model, noise, cfg)
+    ema_obj = state["ema"]
+    optimize_fn = losses.optimization_manager(cfg)
+    train_step_fn = losses.get_step_fn(noise, graph, True, optimize_fn, cfg.training.accum)
+    eval_step_fn = losses.get_step_fn(noise, graph, False, optimize_fn, cfg.training.accum)
+    for s in range(4):
+        loss = train_step_fn(state, g[f"x0_{s}"].to(DEV), t=g[f"t_{s}"].to(DEV), perturbed_batch=g[f"xt_{s}"].to(DEV))
+        assert_close(loss, g["losses"][s], 3e-4, 0, f"loss step {s}")
+        assert state["step"] == s + 1
+    sdm = model.state_dict()
+    for k in ("blocks.0.attn_qkv.weight", "output_layer.linear.bias", "vocab_embed.embedding.weight"):
+        assert_close(sdm[k], g["final." + k], 1e-3, 3e-5, k)
+    names = [n for n, _ in model.named_parameters()]
+    assert state["ema"] is ema_obj and ema_obj.num_updates == 4  # the caller's object, now backed by the flat buffer
+    assert_close(dict(zip(names, ema_obj.shadow_params))["blocks.0.attn_qkv.weight"], g["ema.blocks.0.attn_qkv.weight"],
+                 1e-3, 3e-5)
+    # eval: loss under the EMA weights, training weights back afterwards
+    w_before = {k: v.clone() for k, v in model.state_dict().items()}
+    ev = eval_step_fn(state, g["x0_0"].to(DEV), t=g["t_0"].to(DEV), perturbed_batch=g["xt_0"].to(DEV))
+    assert torch.isfinite(ev)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, w_before[k]), k
+    # checkpoint in the reference's layout through the caller-held objects (utils/utils.py:73-95)
+    path = str(tmp_path / "checkpoint.pth")
+    save_checkpoint(path, state)
+    m_saved = state["trainer"].flat.m.clone()
+    state["trainer"].flat.m.zero_()
+    state["step"] = 0
+    restore_checkpoint(path, state, DEV)
+    assert state["step"] == 4 and torch.equal(state["trainer"].flat.m, m_saved)
+
+
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_ema_copy_to_and_restore_reach_the_compute_weights(cdt):
+    """after `ema.copy_to(model.parameters())` a forward must use the EMA weights in EVERY Linear —
+    the compute-dtype weight cache is keyed on the parameter version — and `ema.restore` must bring the training
+    weights back (reference call sites: losses.py:108-113 eval step, run_train_protlig_cross_att.py:336-379)."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    torch.manual_seed(0)
+    D, H, C, nb, tokens = 128, 2, 128, 2, 25
+    cfg = _cfg(D, H, C, nb, tokens)
+    model = _SEDD(cfg, compute_dtype=cdt).to(DEV)
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=5)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    tr = SEDDTrainer(model, noise, graph, dict(lr=5e-3, warmup=0, grad_clip=1.0), ema_decay=0.5, world_size=1)
+    x0 = torch.randint(0, tokens, (4, 64), device=DEV)
+    for _ in range(3):  # EMA (decay 0.5 / warm-up) now differs clearly from the training weights
+        tr.train_step(x0)
+    xt = torch.randint(0, tokens + 1, (4, 64), device=DEV)
+    sig = torch.rand(4, device=DEV) + 0.2
+    model.eval()
+    with torch.no_grad():
+        train_logits = model(xt, sig).float().clone()
+        # what the EMA weights must give: a fresh model loaded with the shadow parameters
+        fresh = _SEDD(cfg, compute_dtype=cdt).to(DEV).eval()
+        names = [n for n, _ in model.named_parameters()]
+        fresh.load_state_dict({n: s.clone() for n, s in zip(names, tr.ema.shadow_params)}, strict=False)
+        ema_logits = fresh(xt, sig).float()
+        assert rel_err(ema_logits, train_logits) > 1e-3  # the two weight sets are distinguishable
+        tr.ema.store(model.parameters())
+        tr.ema.copy_to(model.parameters())
+        got = model(xt, sig).float()
+        assert torch.equal(got, ema_logits), f"after copy_to: rel err {rel_err(got, ema_logits):.3e} vs the EMA model"
+        tr.ema.restore(model.parameters())
+        back = model(xt, sig).float()
+        assert torch.equal(back, train_logits), "after restore the training weights must be back"
+    model.train()
+    tr.train_step(x0)  # and training continues on the flat buffers
+    assert torch.equal(tr.flat.pc, tr.flat.p.bfloat16()) if cdt == torch.bfloat16 else True
+
+
+def test_adam_l2_and_zero_clip_match_torch():
+    """sedd_adamw_ema_step's two weight-decay forms against torch.optim.Adam (L2, losses.py:36-38) and torch.optim.AdamW
+    (:39-41) over 3 steps, and grad_clip == 0 (clip_grad_norm_(max_norm=0) zeroes the gradients, losses.py:65-66)."""
+    from protein_lig_sedd_amd import ops
+    torch.manual_seed(1)
+    n = 4096
+    for decoupled, cls in ((False, torch.optim.Adam), (True, torch.optim.AdamW)):
+        p_ref = torch.nn.Parameter(torch.randn(n, device=DEV))
+        opt = cls([p_ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1)
+        p = p_ref.detach().clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(1, 4):
+            g = torch.randn(n, device=DEV)
+            p_ref.grad = g.clone()
+            opt.step()
+            ops.adamw_ema_step(p, g, m, v, None, None, None, 1.0, 1e-2, 0.9, 0.99, 1e-8, 0.1, step, 1.0, decoupled)
+            assert_close(p, p_ref.detach(), 1e-5, 1e-6, f"{cls.__name__} step {step}")
+    g = torch.randn(n, device=DEV)
+    out = ops.sumsq_clip(g, 1.0, 0.0)
+    assert float(out[1]) == 0.0
+    out = torch.full((2,), 7.0, device=DEV)
+    ops.sumsq_clip(g, 1.0, -1.0, out=out)
+    assert float(out[1]) == 7.0 and abs(float(out[0]) - float((g.double() ** 2).sum())) < 1e-3 * n

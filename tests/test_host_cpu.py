@@ -101,3 +101,112 @@ def test_trainer_lr_rules():
     assert tr.current_lr(50) == pytest.approx(1e-3)
     tr.lr_schedule = lambda s: warmup_cosine_lr(s, 10, 50)
     assert tr.current_lr(30) == pytest.approx(warmup_cosine_lr(30, 10, 50))
+
+
+def _cross_trainer(task, double_step=True):
+    from types import SimpleNamespace as NS
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd.train import CrossAttTrainer
+    cfg = NS(model=NS(hidden_size=32, cond_dim=16, n_heads=2, n_blocks=1, dropout=0.0, scale_by_sigma=True),
+             graph=NS(type="absorb"))
+    torch.manual_seed(0)
+    model = ProteinLigandDiffusionModel(cfg)
+    tr = CrossAttTrainer(model, noise_lib.LogLinearNoise(), graph_lib.Absorbing(36), graph_lib.Absorbing(2364),
+                         dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, warmup=0, grad_clip=1.0),
+                         task=task, double_step=double_step, world_size=1)
+    return model, tr
+
+
+@pytest.mark.parametrize("task", ["joint", "protein_only", "ligand_only"])
+def test_cross_trainer_checkpoint_round_trip(task):
+    """Adam's own step counter (2 per iteration under double_step, run_train_protlig_cross_att.py:247,325)
+    survives save / load, and the optimizer state is indexed by position in model.parameters() (frozen parameters keep
+    their slot, torch-style), so a task-frozen run's file maps onto the right tensors."""
+    model, tr = _cross_trainer(task)
+    all_params = list(model.parameters())
+    trainable = [i for i, p in enumerate(all_params) if p.requires_grad]
+    if task != "joint":
+        assert 0 < len(trainable) < len(all_params)
+    tr.flat.m.uniform_(-1, 1)
+    tr.flat.v.uniform_(0, 1)
+    tr.step_count, tr.opt_steps, tr.ema.num_updates = 7, 14, 7
+    sd = tr.state_dict()
+    assert sorted(sd["optimizer"]["state"]) == trainable
+    assert all(int(e["step"]) == 14 for e in sd["optimizer"]["state"].values())
+    assert sd["step"] == 7
+    opt = torch.optim.AdamW(all_params, lr=1e-3)
+    opt.load_state_dict(sd["optimizer"])  # torch accepts the layout: one slot per parameter, state only where trained
+    for j, i in enumerate(trainable):
+        assert torch.equal(opt.state[all_params[i]]["exp_avg"], tr.flat.view(tr.flat.m, j))
+    _, tr2 = _cross_trainer(task)
+    tr2.load_state_dict(sd)
+    assert (tr2.step_count, tr2.opt_steps, tr2.ema.num_updates) == (7, 14, 7)
+    for j in range(len(trainable)):
+        assert torch.equal(tr2.flat.view(tr2.flat.m, j), tr.flat.view(tr.flat.m, j))
+        assert torch.equal(tr2.flat.view(tr2.flat.v, j), tr.flat.view(tr.flat.v, j))
+    # a file written by the reference's own optimizer: AdamW over ALL parameters + the noise module's dummy parameter,
+    # stepped twice per iteration; frozen parameters never get a gradient and therefore no state
+    ref_opt = torch.optim.AdamW(all_params + [torch.nn.Parameter(torch.zeros(0))], lr=1e-3)
+    saved_grads = [p.grad for p in all_params]
+    for i in trainable:
+        all_params[i].grad = torch.randn_like(all_params[i])
+    for p in all_params:
+        if not p.requires_grad:
+            p.grad = None
+    ref_opt.step()
+    ref_opt.step()
+    ref_state = ref_opt.state_dict()
+    for p, g in zip(all_params, saved_grads):
+        p.grad = g
+    ref_file = {"optimizer": ref_state, "model": model.state_dict(), "ema": tr.ema.state_dict(), "step": 1}
+    _, tr3 = _cross_trainer(task)
+    tr3.load_state_dict(ref_file)
+    assert (tr3.step_count, tr3.opt_steps) == (1, 2)
+    for j, i in enumerate(trainable):
+        assert torch.equal(tr3.flat.view(tr3.flat.m, j), ref_opt.state[all_params[i]]["exp_avg"])
+        assert torch.equal(tr3.flat.view(tr3.flat.v, j), ref_opt.state[all_params[i]]["exp_avg_sq"])
+
+
+def test_trainer_optimizer_selection():
+    """losses.py:35-46: Adam and AdamW are accepted (the kernel takes the coupled / decoupled weight-decay form), anything
+    else and accum != 1 raise."""
+    from types import SimpleNamespace as NS
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    cfg = NS(model=NS(hidden_size=32, cond_dim=16, n_heads=1, n_blocks=1, dropout=0.0, scale_by_sigma=True, length=8),
+             graph=NS(type="absorb"), tokens=5)
+    mk = lambda **kw: SEDDTrainer(_SEDD(cfg, compute_dtype=torch.float32), noise_lib.LogLinearNoise(),  # noqa: E731
+                                  graph_lib.Absorbing(5), dict(lr=1e-3, **kw), world_size=1)
+    assert mk(optimizer="Adam", weight_decay=0.1).decoupled_wd is False
+    assert mk(optimizer="AdamW").decoupled_wd is True and mk().decoupled_wd is True
+    with pytest.raises(NotImplementedError):
+        mk(optimizer="SGD")
+    with pytest.raises(NotImplementedError):
+        mk(accum=2)
+
+
+def test_g1_product_noise_schedules(golden):
+    """The PRODUCT noise module (protein_lig_sedd_amd/noise_lib.py — host glue on the [B] time vector, so it runs on the
+    CPU as well) against the reference's recorded sigma / dsigma for all three schedules (noise_lib.py:45-94), and
+    get_noise's dispatch + error (noise_lib.py:7-17)."""
+    from types import SimpleNamespace as NS
+    from protein_lig_sedd_amd import noise_lib
+    g = golden("g1_noise")
+    t = g["t"]
+    cases = (("loglinear", NS(type="loglinear", eps=1e-3)), ("loglinear01", NS(type="loglinear", eps=0.1)),
+             ("geometric", NS(type="geometric", sigma_min=1e-4, sigma_max=20.0)),
+             ("cosine", NS(type="cosine", sigma_min=1e-3, sigma_max=1.0)))
+    for name, ncfg in cases:
+        noise = noise_lib.get_noise(NS(noise=ncfg))
+        s, ds = noise(t)
+        assert s.dtype == torch.float32 and ds.dtype == torch.float32
+        np.testing.assert_allclose(s.numpy(), g[name + "_sigma"].numpy(), rtol=1e-6, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(ds.numpy(), g[name + "_dsigma"].numpy(), rtol=1e-6, atol=1e-9, err_msg=name)
+        s2, _ = noise(t[:, None])  # the samplers call with t [B, 1]
+        assert s2.shape == (t.numel(), 1)
+    assert isinstance(noise_lib.get_noise(NS(noise=cases[2][1])).empty, torch.nn.Parameter)  # dummy parameter kept
+    assert len(list(noise_lib.get_noise(NS(noise=cases[3][1])).parameters())) == 0            # Cosine has none
+    with pytest.raises(ValueError):
+        noise_lib.get_noise(NS(noise=NS(type="sqrt")))
