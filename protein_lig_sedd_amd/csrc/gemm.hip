@@ -663,6 +663,10 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                 }
 #undef DGELU_LOAD
                 if (colsum) {
+                    // the block's WM row groups meet in LDS (each wave's staging region is free after its last flush)
+                    // and leave with ONE atomic per column and block, added in a fixed order: with a single row tile
+                    // the sums are bit-reproducible, and the atomic count drops WM-fold
+                    float* mine = reinterpret_cast<float*>(reg);
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -672,9 +676,18 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                             t += __shfl_xor(t, 2, 64);
                             t += __shfl_xor(t, 4, 64);
                             t += __shfl_xor(t, 8, 64);
-                            const int64_t c = col_w + n * 16 + 4 * (lane >> 4) + r;
-                            if ((lane & 15) == 0 && c < N) atomicAdd(colsum + c, t);
+                            if ((lane & 15) == 0) mine[n * 16 + 4 * (lane >> 4) + r] = t;
                         }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (not __syncthreads(): it would also wait for
+                    __builtin_amdgcn_s_barrier();                       //  the tile's stores and the next tile's DMA)
+                    if (wm == 0) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WM; ++w)
+                            t += reinterpret_cast<const float*>(stage_lds + (w * WN + wn) * SC::REGION)[lane];
+                        const int64_t c = col_w + lane;
+                        if (c < N) atomicAdd(colsum + c, t);
+                    }
                 }
             } else {
             // ROT: the cos / sin rows of pass p+RPD are requested while pass p is rotated, staged and stored
