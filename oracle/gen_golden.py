@@ -39,11 +39,14 @@ def _install_stubs():
         total, three, H, d = qkv.shape
         B = cu_seqlens.numel() - 1
         L = total // B
-        q, k, v = qkv.view(B, L, 3, H, d).float().unbind(2)
-        s = torch.einsum("blhd,bmhd->bhlm", q, k) * (d ** -0.5)
-        p = torch.softmax(s, dim=-1)
-        o = torch.einsum("bhlm,bmhd->blhd", p, v)
-        return o.reshape(total, H, d).to(qkv.dtype)
+        # a custom op: autocast only decides the dtype of what comes in, never the arithmetic inside (matters for g17,
+        # where the caller's region runs under CPU autocast and einsum would otherwise be demoted to bf16)
+        with torch.autocast("cpu", enabled=False):
+            q, k, v = qkv.view(B, L, 3, H, d).float().unbind(2)
+            s = torch.einsum("blhd,bmhd->bhlm", q, k) * (d ** -0.5)
+            p = torch.softmax(s, dim=-1)
+            o = torch.einsum("bhlm,bmhd->blhd", p, v)
+            return o.reshape(total, H, d).to(qkv.dtype)
 
     fai.flash_attn_varlen_qkvpacked_func = flash_attn_varlen_qkvpacked_func
     ops = types.ModuleType("flash_attn.ops")
@@ -737,6 +740,135 @@ def g16_cross_train_trajectory():
     save("g16_cross_train_trajectory", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G17
+class _CpuBf16Autocast:
+    """Runs the reference's own `torch.cuda.amp.autocast(...)` regions (transformer.py:36, 169, 306-311) as CPU autocast:
+    without CUDA the reference's contexts are inert and its forward is plain fp32, so the bf16 rounding points of the
+    autocast region would otherwise be pinned by nothing but this build's restatement.  `torch.cuda.amp.autocast` is
+    looked up at call time, so swapping the attribute for the duration of a forward reroutes every use — including the
+    `enabled=False` islands around LayerNorm and rotary — with no change to the reference's code."""
+
+    def __enter__(self):
+        self.saved = torch.cuda.amp.autocast
+        torch.cuda.amp.autocast = lambda dtype=torch.bfloat16, enabled=True, **kw: torch.autocast(
+            "cpu", dtype=dtype or torch.bfloat16, enabled=enabled)
+        return self
+
+    def __exit__(self, *a):
+        torch.cuda.amp.autocast = self.saved
+        return False
+
+
+def g17_bf16_autocast():
+    """The reference under bf16 autocast (CPU autocast standing in for CUDA autocast; both cast nn.Linear / matmul
+    operands and results to bf16 and leave the explicitly-disabled islands in fp32): one flash-variant DDiTBlock
+    (forward + gradients, entered under the same autocast context SEDD.forward opens, transformer.py:306) and the
+    mini `_SEDD` (logits, loss, gradients).  Known difference between the two autocast op lists that matters here: none
+    on this path — every op between the Linears (modulate, GELU, gate/residual) is elementwise and runs in its input
+    dtype under either backend; LayerNorm and rotary run inside the reference's own `enabled=False` islands."""
+    torch.manual_seed(117)
+    out = {}
+    D, H, C, B, L = 128, 2, 64, 2, 80
+    blk = ref_tf.DDiTBlock(D, H, C, dropout=0.0)
+    load_seeded(blk, seed=8, std=0.05)
+    blk.eval()
+    x = torch.randn(B, L, D, requires_grad=True)
+    c = torch.randn(B, C, requires_grad=True)
+    rot = ref_rotary.Rotary(D // H)
+    cos, sin = rot(x)
+    with _CpuBf16Autocast():
+        with torch.cuda.amp.autocast(dtype=torch.bfloat16):
+            y = blk(x, (cos, sin), c)
+    w = torch.randn(B, L, D)
+    (y.float() * w).sum().backward()
+    t = "block_"
+    out.update({t + "x": x, t + "c": c, t + "y": y.float(), t + "w": w, t + "dx": x.grad, t + "dc": c.grad,
+                t + "dims": np.array([D, H, C, B, L]), t + "y_is_fp32": np.array(int(y.dtype == torch.float32))})
+    for n, p in blk.named_parameters():
+        out[t + "grad." + n] = p.grad
+    graph = graph_lib.Absorbing(25)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    cfg, B, L = sedd_config(128, 4, 64, 2), 3, 64
+    model = ref_tf._SEDD(cfg)
+    load_seeded(model, seed=10)
+    model.eval()
+    x0, tt, u = _loss_inputs(B, L, 26, 1017)
+    sigma, dsigma = noise(tt)
+    xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 25), x0)
+    with _CpuBf16Autocast():
+        logits = quiet(model, xt, sigma)
+        loss = quiet(losses.get_loss_fn(noise, graph, train=False), _KwDrop(model), x0, t=tt, perturbed_batch=xt)
+    model.zero_grad()
+    loss.backward()
+    t = "mini_"
+    out.update({t + "x0": x0, t + "t": tt, t + "xt": xt, t + "sigma": sigma, t + "logits": logits.float(),
+                t + "logits_is_bf16": np.array(int(logits.dtype == torch.bfloat16)), t + "loss": loss.float(),
+                t + "cfg": np.array([cfg.model.hidden_size, cfg.model.n_heads, cfg.model.cond_dim, cfg.model.n_blocks,
+                                     cfg.tokens])})
+    for n, p in model.named_parameters():
+        out[t + "grad." + n] = p.grad
+    save("g17_bf16_autocast", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G18
+def g18_conditional_sampling():
+    """the two conditional-sampling front-ends, run through the reference's own get_pc_sampler loop with the
+    noise it draws recorded.
+      (a) infilling (sampling/run_sample_cond.py:32-44): `proj_fun` clamps a prefix and a suffix before every update, the
+          caller applies it once more to the result;
+      (b) `ligand_given_protein` / `protein_given_ligand` on the dual-track model (sampling.py:64-76: the conditioning
+          track's indices ride along, transformers_protlig_cross.py:596-642 builds the cross-attention context)."""
+    out = {}
+    cfg = sedd_config(128, 4, 64, 2)
+    model = ref_tf._SEDD(cfg)
+    load_seeded(model, seed=13, std=0.1)
+    graph = graph_lib.Absorbing(25)
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    B, L, steps = 3, 40, 6
+    gen = torch.Generator().manual_seed(118)
+    prefix = torch.randint(0, 25, (5,), generator=gen)
+    suffix = torch.randint(0, 25, (7,), generator=gen)
+    input_locs = list(range(len(prefix))) + list(range(L - len(suffix), L))
+    input_ids = torch.cat([prefix, suffix])[None].repeat(B, 1)
+
+    def proj_fun(x):
+        x[:, input_locs] = input_ids
+        return x
+
+    for pred_name in ("euler",):
+        torch.manual_seed(118)
+        sampler = sampling.get_pc_sampler(graph, noise, (B, L), pred_name, steps, denoise=True, eps=1e-5, proj_fun=proj_fun)
+        with RecordRand() as rr:
+            x = proj_fun(quiet(sampler, _SamplerModel(model), "protein_only"))
+        out["infill_out"] = x
+        out["infill_u"] = torch.stack([r for _, r in rr.log[:steps]])
+        out["infill_u_denoise"] = rr.log[steps][1]
+    out.update({"infill_cfg": np.array([128, 4, 64, 2, 25]), "infill_dims": np.array([B, L, steps]),
+                "infill_locs": np.array(input_locs), "infill_ids": input_ids})
+    # (b) conditional tracks of the dual-track model
+    ccfg = cross_config(64, 2, 32, 2)
+    cm = ref_cross.ProteinLigandDiffusionModel(ccfg)
+    load_seeded(cm, seed=11, std=0.05)
+    cm.eval()
+    B, Lp, Ll, steps = 3, 24, 16, 5
+    gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+    prot = torch.randint(0, 33, (B, Lp), generator=gen)
+    lig = torch.randint(0, 2362, (B, Ll), generator=gen)
+    out.update({"cond_cfg": np.array([64, 2, 32, 2]), "cond_dims": np.array([B, Lp, Ll, steps]), "cond_prot": prot,
+                "cond_lig": lig})
+    torch.manual_seed(218)
+    sampler = sampling.get_pc_sampler(gl, noise, (B, Ll), "euler", steps, denoise=True, eps=1e-5)
+    with RecordRand() as rr:
+        x = quiet(sampler, cm, "ligand_given_protein", prot, None)
+    out["lgp_out"], out["lgp_u"], out["lgp_u_denoise"] = x, torch.stack([r for _, r in rr.log[:steps]]), rr.log[steps][1]
+    torch.manual_seed(318)
+    sampler = sampling.get_pc_sampler(gp, noise, (B, Lp), "euler", steps, denoise=True, eps=1e-5)
+    with RecordRand() as rr:
+        x = quiet(sampler, cm, "protein_given_ligand", None, lig)
+    out["pgl_out"], out["pgl_u"], out["pgl_u_denoise"] = x, torch.stack([r for _, r in rr.log[:steps]]), rr.log[steps][1]
+    save("g18_conditional_sampling", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -744,7 +876,7 @@ def main():
     for fn in (g1_noise, g2_sample_transition, g3_score_entropy, g4_graph_ops, g5_sample_categorical,
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
                g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule,
-               g16_cross_train_trajectory):
+               g16_cross_train_trajectory, g17_bf16_autocast, g18_conditional_sampling):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

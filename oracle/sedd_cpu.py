@@ -270,7 +270,11 @@ def ddit_block(sd, pre, x, c, n_heads, bf16=False):
     B, L, D = x.shape
     d = D // n_heads
     mod = _linear(c, sd[pre + "adaLN_modulation.weight"], sd[pre + "adaLN_modulation.bias"], bf16)
-    sh1, sc1, g1, sh2, sc2, g2 = mod[:, None].chunk(6, dim=2)
+    # modulate_fused / bias_dropout_add_scale_fused are TorchScript-fused in the reference (fused_add_dropout_scale.py:
+    # 7-10 turns the fusers on): inside a fused kernel bf16 operands are widened once and the arithmetic stays fp32,
+    # so `1 + scale` and `scale * x` are NOT rounded to bf16 on the way (pinned by golden g17: the reference under bf16
+    # autocast)
+    sh1, sc1, g1, sh2, sc2, g2 = mod.float()[:, None].chunk(6, dim=2)
     h = layer_norm_w(x, sd[pre + "norm1.weight"]) * (1 + sc1) + sh1
     qkv = _linear(h, sd[pre + "attn_qkv.weight"], None, bf16).view(B, L, 3, n_heads, d)
     cos, sin = rotary_cos_sin(L, d)
@@ -278,17 +282,17 @@ def ddit_block(sd, pre, x, c, n_heads, bf16=False):
     q, k, v = qkv.unbind(2)
     q, k = apply_rotary(q, cos, sin), apply_rotary(k, cos, sin)
     o = softmax_attention(q, k, v).reshape(B, L, D)
-    x = x + g1 * _linear(o, sd[pre + "attn_out.weight"], None, bf16)
+    x = x + g1 * _linear(o, sd[pre + "attn_out.weight"], None, bf16).float()
     h = layer_norm_w(x, sd[pre + "norm2.weight"]) * (1 + sc2) + sh2
     h = _linear(h, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], bf16)
     h = _linear(F.gelu(h, approximate="tanh"), sd[pre + "mlp.2.weight"], sd[pre + "mlp.2.bias"], bf16)
-    return x + g2 * h
+    return x + g2 * h.float()
 
 
 def final_layer(sd, pre, x, c, bf16=False):
     """DDitFinalLayer.forward (transformer.py:234-238)"""
     mod = _linear(c, sd[pre + "adaLN_modulation.weight"], sd[pre + "adaLN_modulation.bias"], bf16)
-    sh, sc = mod[:, None].chunk(2, dim=2)
+    sh, sc = mod.float()[:, None].chunk(2, dim=2)
     h = layer_norm_w(x, sd[pre + "norm_final.weight"]) * (1 + sc) + sh
     return _linear(h, sd[pre + "linear.weight"], sd[pre + "linear.bias"], bf16)
 

@@ -186,9 +186,34 @@ class ProteinLigandDiffusionModel(nn.Module):
         self.transformer = DualTrackDiffusionTransformer(config, vocab_size_protein, vocab_size_ligand,
                                                          compute_dtype=compute_dtype,
                                                          seq_axis_attention=seq_axis_attention)
+        self._ctx_step, self._ctx_cache, self.context_cache_hits = None, {}, 0
+
+    # ---- per-step context cache for the *_given_* sampling modes -----------------------------------------
+    def sampling_step(self, step):
+        """Called by sampling.get_pc_sampler's loop: `step` = index of the sampler update about to run (None = sampling
+        over).  The conditioning context depends on sigma(t_step), so it is valid for ONE step only: every model call
+        of that step with the same conditioning indices (a predictor followed by a corrector, both conditional tracks
+        evaluated per step, ...) reuses it instead of re-running the conditioning track's n_blocks // 2 blocks; a new
+        step (or None) drops it."""
+        if step != self._ctx_step:
+            self._ctx_step, self._ctx_cache = step, {}
 
     def _context(self, indices, timesteps, track):
         """first n_blocks // 2 blocks of the conditioning track without cross-attention (:608-616, :636-642)."""
+        key = None
+        if self._ctx_step is not None and not torch.is_grad_enabled() and not self.training:
+            # (the caller holds `indices` for the whole sampling run, so its storage identifies the conditioning input)
+            key = (track, indices.data_ptr(), indices._version, tuple(indices.shape))
+            hit = self._ctx_cache.get(key)
+            if hit is not None:
+                self.context_cache_hits += 1
+                return hit
+        h = self._context_uncached(indices, timesteps, track)
+        if key is not None:
+            self._ctx_cache[key] = h
+        return h
+
+    def _context_uncached(self, indices, timesteps, track):
         tr = self.transformer
         embed, blocks = (tr.protein_embed, tr.blocks_prot) if track == "protein" else (tr.ligand_embed, tr.blocks_lig)
         h = embed(indices)

@@ -145,18 +145,25 @@ def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps
         timesteps = torch.linspace(1, eps, steps + 1, device=device)
         dt = (1 - eps) / steps
         ones = torch.ones(x.shape[0], 1, device=device)
-        for i in range(steps):
-            t = timesteps[i] * ones
-            x = projector(x)
-            u = None if noise_seq is None else noise_seq[i]
-            x = predictor.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
-                                    lig_indices=lig_indices, u=u)
-        if denoise:
-            x = projector(x)
-            t = timesteps[-1] * ones
-            u = None if noise_seq is None else noise_seq[steps]
-            x = denoiser.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
-                                   lig_indices=lig_indices, u=u)
+        mark = getattr(model, "sampling_step", None)  # dual-track model: per-step cache of the conditioning context
+        mark = mark if callable(mark) else (lambda i: None)
+        try:
+            for i in range(steps):
+                mark(i)
+                t = timesteps[i] * ones
+                x = projector(x)
+                u = None if noise_seq is None else noise_seq[i]
+                x = predictor.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
+                                        lig_indices=lig_indices, u=u)
+            if denoise:
+                mark(steps)
+                x = projector(x)
+                t = timesteps[-1] * ones
+                u = None if noise_seq is None else noise_seq[steps]
+                x = denoiser.update_fn(score_model=model, x=x, t=t, step_size=dt, task=task, prot_indices=prot_indices,
+                                       lig_indices=lig_indices, u=u)
+        finally:
+            mark(None)  # the context cache never outlives the run, also when an update raises
         return x
 
     return pc_sampler

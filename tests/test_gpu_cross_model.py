@@ -240,3 +240,92 @@ def test_cfg3_dimensions_match_the_oracle():
         got_po = model(protein_indices=ptd, timesteps=sg, mode="protein_only")
     assert rel_err(got_po, ref_po) < 1e-4
     assert_close(got_po, ref_po, 1e-4, 2e-4, "protein_only logits")
+
+
+def test_g18_conditional_sampling_bit_exact(golden):
+    """SURVEY 8(f2) through the product sampler, against runs of the reference's own get_pc_sampler loop with its noise
+    recorded (golden g18): (a) infilling — proj_fun clamps a prefix and a suffix before every update
+    (sampling/run_sample_cond.py:32-44); (b) ligand_given_protein / protein_given_ligand on the dual-track model
+    (sampling.py:64-76).  Sampled indices bit-exact for identical noise."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib, sampling
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from test_oracle_vs_golden import sedd_shapes
+    g = golden("g18_conditional_sampling")
+    noise = noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    D, H, C, nb, tokens = g["infill_cfg"].tolist()
+    B, L, steps = g["infill_dims"].tolist()
+    ns = types.SimpleNamespace
+    model = _SEDD(ns(tokens=tokens, graph=ns(type="absorb"),
+                     model=ns(hidden_size=D, cond_dim=C, n_heads=H, n_blocks=nb, dropout=0.0, scale_by_sigma=True)),
+                  compute_dtype=torch.float32).to(DEV)
+    load_sd(model, seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=13, std=0.1))
+    locs, ids = g["infill_locs"].tolist(), g["infill_ids"].to(DEV)
+
+    def proj_fun(x):
+        x[:, locs] = ids
+        return x
+
+    sampler = sampling.get_pc_sampler(graph_lib.Absorbing(tokens), noise, (B, L), "euler", steps, denoise=True, eps=1e-5,
+                                      device=DEV, proj_fun=proj_fun)
+    seq = [u.to(DEV) for u in g["infill_u"]] + [g["infill_u_denoise"].to(DEV)]
+    out = proj_fun(sampler(model, noise_seq=seq))
+    assert int((out.cpu() != g["infill_out"]).sum()) == 0
+    assert torch.equal(out[:, locs], ids)
+    # the Analytic predictor honours the same clamp (no golden: the reference's loop cannot call it, quirk Q5)
+    out = proj_fun(sampling.get_pc_sampler(graph_lib.Absorbing(tokens), noise, (B, L), "analytic", steps, device=DEV,
+                                           proj_fun=proj_fun)(model))
+    assert torch.equal(out[:, locs], ids) and int(((out < 0) | (out >= tokens)).sum()) == 0
+    # (b) conditional tracks
+    D, H, C, nb = g["cond_cfg"].tolist()
+    B, Lp, Ll, steps = g["cond_dims"].tolist()
+    cm = ProteinLigandDiffusionModel(_cfg(D, H, C, nb)).to(DEV).eval()
+    load_sd(cm, seeded_state_dict(cross_shapes(D, C, nb), seed=11, std=0.05))
+    prot, lig = g["cond_prot"].to(DEV), g["cond_lig"].to(DEV)
+    for tag, gr, Lx, kw in (("lgp", graph_lib.Absorbing(2364), Ll, dict(task="ligand_given_protein", prot_indices=prot)),
+                            ("pgl", graph_lib.Absorbing(36), Lp, dict(task="protein_given_ligand", lig_indices=lig))):
+        sampler = sampling.get_pc_sampler(gr, noise, (B, Lx), "euler", steps, denoise=True, eps=1e-5, device=DEV)
+        seq = [u.to(DEV) for u in g[tag + "_u"]] + [g[tag + "_u_denoise"].to(DEV)]
+        out = sampler(cm, noise_seq=seq, **kw)
+        assert int((out.cpu() != g[tag + "_out"]).sum()) == 0, tag
+    assert cm._ctx_step is None and cm._ctx_cache == {}  # the per-step context cache does not outlive a run
+
+
+def test_context_cache_is_per_step():
+    """SURVEY 8(f2) context caching: within one sampler step every call with the same conditioning indices reuses the
+    conditioning track's context (its n_blocks // 2 blocks run once); the next step recomputes it (it depends on
+    sigma); outside a sampler run, in training mode or under autograd nothing is cached.  Results unchanged."""
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    torch.manual_seed(1)
+    D, H, C, nb, B, Lp, Ll = 64, 2, 32, 2, 2, 24, 16
+    cm = ProteinLigandDiffusionModel(_cfg(D, H, C, nb)).to(DEV).eval()
+    load_sd(cm, seeded_state_dict(cross_shapes(D, C, nb), seed=11, std=0.05))
+    prot = torch.randint(0, 33, (B, Lp), device=DEV)
+    lig = torch.randint(0, 2362, (B, Ll), device=DEV)
+    s1, s2 = torch.full((B,), 0.7, device=DEV), torch.full((B,), 0.3, device=DEV)
+    calls = []
+    orig = cm._context_uncached
+    cm._context_uncached = lambda *a: (calls.append(1), orig(*a))[1]
+    with torch.no_grad():
+        base1 = cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
+        base2 = cm(protein_indices=prot, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
+        assert len(calls) == 2 and cm.context_cache_hits == 0          # no sampler run: never cached
+        cm.sampling_step(0)
+        a = cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
+        b = cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
+        assert len(calls) == 3 and cm.context_cache_hits == 1          # second call of the step reuses the context
+        assert torch.equal(a, base1) and torch.equal(b, base1)
+        cm.sampling_step(1)                                            # new step = new sigma: recomputed
+        c = cm(protein_indices=prot, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
+        assert len(calls) == 4 and torch.equal(c, base2)
+        prot2 = prot.clone()                                           # other conditioning input: its own entry
+        cm(protein_indices=prot2, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
+        assert len(calls) == 5
+        cm.sampling_step(None)
+        assert cm._ctx_cache == {}
+    cm.sampling_step(0)
+    cm.train()
+    cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
+    cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
+    assert len(calls) == 7 and cm.context_cache_hits == 1              # training / autograd: no caching
+    cm.sampling_step(None)

@@ -206,3 +206,43 @@ def test_g13_pc_sampler_bit_exact(golden):
     assert int((a.cpu() != g["analytic_steps"][0]).sum()) == 0
     with pytest.raises(KeyError):
         sampling.get_predictor("bogus")
+
+
+def test_g17_bf16_path_vs_the_reference_under_autocast(golden):
+    """The HIP bf16 compute path against the REFERENCE ITSELF under bf16 autocast (golden g17: the reference's autocast
+    region run with CPU autocast, oracle/gen_golden.py) — block output and gradients, model logits, loss and gradients,
+    at north_star's bf16 bound 2e-2.  The kernels round less often than the reference (rotary and GELU are applied to
+    fp32 accumulators in GEMM epilogues), so agreement is to bf16 accuracy, not bitwise."""
+    from protein_lig_sedd_amd.model.transformer import DDiTBlock, _SEDD
+    from protein_lig_sedd_amd.model.rotary import Rotary
+    from protein_lig_sedd_amd import graph_lib, noise_lib, losses
+    g = golden("g17_bf16_autocast")
+    D, H, C, B, L = g["block_dims"].tolist()
+    blk = DDiTBlock(D, H, C, dropout=0.0, compute_dtype=torch.bfloat16).to(DEV)
+    load_sd(blk, seeded_state_dict(_block_shapes(D, C), seed=8, std=0.05))
+    x = g["block_x"].to(DEV).requires_grad_(True)
+    c = g["block_c"].to(DEV).requires_grad_(True)
+    rot = Rotary(D // H).to(DEV)
+    y = blk(x, rot(x), c)
+    assert y.dtype == torch.float32
+    # the block output is residual + update: judge the update (y - x), the part the bf16 arithmetic produces
+    assert rel_err(y - x.detach(), g["block_y"] - g["block_x"]) < 2e-2
+    (y * g["block_w"].to(DEV)).sum().backward()
+    assert rel_err(x.grad, g["block_dx"]) < 2e-2 and rel_err(c.grad, g["block_dc"]) < 2e-2
+    for k, p in blk.named_parameters():
+        assert rel_err(p.grad, g["block_grad." + k]) < 2e-2, k
+    D, H, C, nb, tokens = g["mini_cfg"].tolist()
+    model = _SEDD(sedd_config(D, H, C, nb, tokens), compute_dtype=torch.bfloat16).to(DEV)
+    load_sd(model, seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=10))
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    x0, t, xt = g["mini_x0"].to(DEV), g["mini_t"].to(DEV), g["mini_xt"].to(DEV)
+    model.train()
+    logits = model(xt, noise(t)[0])
+    assert logits.dtype == torch.bfloat16
+    assert rel_err(logits.float(), g["mini_logits"]) < 2e-2
+    loss = losses.get_loss_fn(noise, graph, train=True)(model, x0, t=t, perturbed_batch=xt)
+    assert_close(loss, g["mini_loss"], 2e-2, 0, "loss")
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = g["mini_grad." + k]
+        assert rel_err(p.grad, ref) < 3e-2, f"{k}: {rel_err(p.grad, ref):.3e}"

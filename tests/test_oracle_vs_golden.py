@@ -326,3 +326,79 @@ def test_g14_ema(golden):
         O.ema_update(sb, g["bs"][s], d)
     assert_close(sw, g["shadow_w"], 1e-6, 1e-7)
     assert_close(sb, g["shadow_b"], 1e-6, 1e-7)
+
+
+def test_g17_bf16_autocast_pins_the_oracles_rounding_points(golden):
+    """g17 = the REFERENCE under bf16 autocast (its own autocast regions run as CPU autocast, oracle/gen_golden.py).  The
+    oracle's bf16 restatement (`bf16=True`: Linear inputs / weights / outputs rounded to bf16; LayerNorm, softmax in fp32;
+    rotary op-by-op in bf16; the TorchScript-fused modulate / gated residual widened once and kept in fp32) reproduces it
+    BIT FOR BIT — block output, every gradient, model logits — i.e. the rounding points sit where the reference's do.
+    (The loss differs at bf16 level: the reference evaluates score_entropy's exp / sum on the bf16 logits in bf16, the
+    oracle and the HIP kernel widen to fp32 first; bound 2e-2 per north_star.)"""
+    g = golden("g17_bf16_autocast")
+    D, H, C, B, L = g["block_dims"].tolist()
+    assert int(g["block_y_is_fp32"]) == 1 and int(g["mini_logits_is_bf16"]) == 1  # residual fp32, logits bf16
+    sd = {k: v.clone().requires_grad_(True) for k, v in seeded_state_dict(_block_shapes(D, C), seed=8, std=0.05).items()}
+    x, c = g["block_x"].clone().requires_grad_(True), g["block_c"].clone().requires_grad_(True)
+    y = O.ddit_block(sd, "", x, c, H, bf16=True)
+    (y.float() * g["block_w"]).sum().backward()
+    assert torch.equal(y.detach().float(), g["block_y"])
+    assert torch.equal(x.grad, g["block_dx"]) and torch.equal(c.grad, g["block_dc"])
+    for k, v in sd.items():
+        assert_close(v.grad, g["block_grad." + k], 1e-6, 1e-9, k)
+    with torch.no_grad():  # the fp32 path is measurably different from the bf16 golden: the fixture discriminates
+        y32 = O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g["block_x"], g["block_c"], H, bf16=False)
+    assert float((y32 - g["block_y"]).norm() / g["block_y"].norm()) > 3e-4
+    D, H, C, nb, tokens = g["mini_cfg"].tolist()
+    msd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=10)
+    graph, noise = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
+    loss, logits = O.sedd_loss(msd, graph, noise, g["mini_x0"], g["mini_t"], g["mini_xt"], H, nb, bf16=True)
+    assert logits.dtype == torch.bfloat16
+    assert torch.equal(logits.float(), g["mini_logits"])
+    assert_close(loss, g["mini_loss"], 2e-2, 0, "loss")
+
+
+def test_g18_conditional_sampling(golden):
+    """The oracle replays the reference's conditional sampler runs bit-exactly: infilling through proj_fun
+    (run_sample_cond.py:32-44) and the *_given_* modes of the dual-track model (sampling.py:64-76)."""
+    g = golden("g18_conditional_sampling")
+    noise = O.make_noise("loglinear", eps=1e-3)
+    D, H, C, nb, tokens = g["infill_cfg"].tolist()
+    B, L, steps = g["infill_dims"].tolist()
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=13, std=0.1)
+    graph = O.AbsorbingCPU(tokens)
+    locs, ids = g["infill_locs"].tolist(), g["infill_ids"]
+    ts = torch.linspace(1, 1e-5, steps + 1)
+    dt = (1 - 1e-5) / steps
+    with torch.no_grad():
+        x = graph.sample_limit(B, L)
+        for i in range(steps):
+            x[:, locs] = ids
+            sg = noise(ts[i] * torch.ones(B, 1))
+            x = O.euler_step(graph, O.sedd_forward(sd, x, sg[0].reshape(-1), H, nb), x, sg, dt, g["infill_u"][i])
+        x[:, locs] = ids
+        sg = noise(ts[-1] * torch.ones(B, 1))[0]
+        x = O.denoise_step(graph, O.sedd_forward(sd, x, sg.reshape(-1), H, nb), x, sg, g["infill_u_denoise"])
+        x[:, locs] = ids
+    assert torch.equal(x, g["infill_out"])
+    assert torch.equal(g["infill_out"][:, locs], ids)  # the clamp holds in the reference's own output
+    D, H, C, nb = g["cond_cfg"].tolist()
+    B, Lp, Ll, steps = g["cond_dims"].tolist()
+    csd = seeded_state_dict(cross_shapes(D, C, nb), seed=11, std=0.05)
+    ts = torch.linspace(1, 1e-5, steps + 1)
+    dt = (1 - 1e-5) / steps
+    for tag, track, cond_track, cond, tok, Lx in (("lgp", "ligand", "protein", g["cond_prot"], 2364, Ll),
+                                                  ("pgl", "protein", "ligand", g["cond_lig"], 36, Lp)):
+        graph = O.AbsorbingCPU(tok)
+        with torch.no_grad():
+            x = graph.sample_limit(B, Lx)
+            for i in range(steps + 1):
+                sg = noise(ts[i] * torch.ones(B, 1))
+                sig = sg[0].reshape(-1)
+                ctx = O.cross_context(csd, cond, sig, cond_track, H, nb)
+                logits = O.cross_single_track(csd, x, sig, track, H, nb, other=ctx)
+                if i < steps:
+                    x = O.euler_step(graph, logits, x, sg, dt, g[tag + "_u"][i])
+                else:
+                    x = O.denoise_step(graph, logits, x, sg[0], g[tag + "_u_denoise"])
+        assert torch.equal(x, g[tag + "_out"]), tag
