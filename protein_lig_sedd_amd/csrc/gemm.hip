@@ -97,6 +97,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Persistent tile t (t % 8 = the XCD that runs it under round-robin dispatch; speed only, never correctness) -> tile
+// coordinates.  csplit == 1: every XCD owns a contiguous run of row panels, all column tiles of a panel back to back
+// (the A row panel is fetched into ONE L2).  csplit = S > 1: the XCDs form an (8 / S) x S grid, XCD (xr, xc) owns the
+// rows of group xr and the column tiles of slice xc, column index fastest: its slice of the weight (B / S bytes, chosen
+// to fit the 4 MiB L2 beside the streams) stays resident for the whole launch instead of being re-fetched from the
+// fabric every round, at the price of S XCDs reading each A panel (see choose_csplit).
+__device__ __forceinline__ void big_tile_map(int tile, int ntiles, int ntn, int csplit, bool linear, int& tm, int& tn) {
+    if (linear) { tm = tile / ntn; tn = tile % ntn; return; }
+    if (csplit <= 1) {
+        const int wg = xcd_remap(tile, ntiles);
+        tm = wg / ntn; tn = wg % ntn;
+        return;
+    }
+    const int xcd = tile & 7, idx = tile >> 3;
+    const int cn = ntn / csplit, rn = (ntiles / ntn) / (8 / csplit);
+    const int xr = xcd / csplit, xc = xcd % csplit;
+    tm = xr * rn + idx / cn;
+    tn = xc * cn + idx % cn;
+}
+
 template <typename TO> __device__ __forceinline__ void store_row4(TO* p, f32x4 v);
 template <> __device__ __forceinline__ void store_row4<float>(float* p, f32x4 v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -373,9 +393,11 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             TO* __restrict__ C, int64_t ldc,
                                                             const float* __restrict__ bias, int epi,
                                                             TO* __restrict__ pre, int accumulate, int64_t M,
-                                                            int64_t N, int64_t Kper, int64_t Ktot, int ntn,
+                                                            int64_t N, int64_t Kper, int64_t Ktot, int ntn_cs,
                                                             int ntiles, int splitk, float4* __restrict__ slabs,
                                                             float* __restrict__ colsum, RotArgs rot) {
+    // ntn_cs = column tiles | (column split of the XCD map << 20), see big_tile_map / choose_csplit
+    const int ntn = ntn_cs & 0xfffff, csplit = ntn_cs >> 20;
     constexpr int WN = BN_ / 64, WM = NW / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
     constexpr int LA = BIG_BM / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
     constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;                 // K-loop unroll: whole ring turns, even
@@ -422,9 +444,10 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     int64_t m0 = 0, n0 = 0;
 #define BIG_TILE_SETUP(tile)                                                                                         \
     do {                                                                                                             \
-        const int wg_ = splitk > 1 ? (int)(tile) : xcd_remap((int)(tile), ntiles);                                   \
-        m0 = (int64_t)(wg_ / ntn) * BIG_BM;                                                                          \
-        n0 = (int64_t)(wg_ % ntn) * BN_;                                                                             \
+        int tm_, tn_;                                                                                                \
+        big_tile_map((int)(tile), ntiles, ntn, csplit, splitk > 1, tm_, tn_);                                        \
+        m0 = (int64_t)tm_ * BIG_BM;                                                                                  \
+        n0 = (int64_t)tn_ * BN_;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
             if constexpr (TA) { /* wave-instruction j = 2 token rows x 512 B */                                      \
                 const int r = (i * NW + wave) * 2 + (lane >> 5);                                                      \
@@ -963,6 +986,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float4* __rest
     }
 }
 
+// Column split of the XCD tile map (big_tile_map) for a multi-round NT / NN launch: modelled fabric reads =
+// S x (A bytes: every A panel is read by S XCDs) + B traffic, where a B slice of <= 2.5 MB stays L2-resident (read once
+// per XCD) and a larger one is streamed again every round.  fc1 forward (A 50 MB, B 4.7 MB, 6 rounds): S = 1 -> 276 MB
+// (measured 294), S = 2 -> 119 MB.
+static int choose_csplit(int64_t tm, int64_t tn, int64_t tiles, int64_t M, int64_t N, int64_t K) {
+    static const char* ov = getenv("SEDD_GEMM_CSPLIT");
+    if (tiles < 512 || tiles % 8) return 1;
+    const double A = 2.0 * (double)M * (double)K, B = 2.0 * (double)N * (double)K, rounds = (double)tiles / 256.0;
+    int best = 1;
+    double bc = 1e300;
+    for (int S = 1; S <= 4; S *= 2) {
+        if (tn % S || tm % (8 / S)) continue;
+        if (ov && atoi(ov) != S) continue;
+        const double bs = B / S, cost = S * A + (bs <= 2.5e6 ? 8.0 * bs : rounds * 8.0 * bs);
+        if (cost < bc) { bc = cost; best = S; }
+    }
+    return best;
+}
+
 // split-K plan for accumulating fp32 outputs with too few tiles for the 256 CUs: as many K slices as keep
 // tiles * slices <= 256 (one round of persistent blocks), every slice a whole number of K tiles, at least 16 of them
 static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
@@ -1033,13 +1075,15 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             // 256-wide one spills with even one); same-box A/B at N = 2304: equal step time, so the narrow tile it is
             if (rot) wide = false;
             const int bn = wide ? 256 : 128;
-            const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
+            int64_t tn = (N + bn - 1) / bn;
+            const int64_t tiles = tm * tn;
             int64_t kper = K;
             int splitk = 1;
             if (accumulate && out_dtype == SEDD_F32) big_splitk(tiles, K, &splitk, &kper);
             SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_nt: too many tiles");
             // one persistent block per CU (the operand ring takes most of a CU's LDS)
             const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
+            if (splitk == 1) tn |= (int64_t)choose_csplit(tm, tn, tiles, M, N, K) << 20;  // (tn is only passed on from here)
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \

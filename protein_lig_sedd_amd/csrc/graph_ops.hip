@@ -11,6 +11,7 @@
 // Floating-point contraction is off in this file so that every product/sum rounds exactly like the reference's
 // op-by-op torch arithmetic (needed for bit-exact sampled indices).
 #include "common.h"
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 #define TPB 256
@@ -592,8 +593,16 @@ __global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step
     }
 }
 
-// (A persistent, double-buffered variant of this kernel measured slower: the arithmetic — exp, log and an IEEE
-// division per vocabulary entry — needs the occupancy that one small tile per block gives.)
+// What bounds this kernel (round-2 measurements at the cfg-5 shard, 512 x 1024 rows, V = 26, bf16; 90 MB algorithmic):
+// LDS-DMA alone moves the tiles in 13.5 us, but SQ_INSTS_VALU is 11.4 M wave-instructions per launch — ~2000 per
+// surviving row (OCML expf 13, compensated log 9, IEEE division 11, selects / compares / moves ~25 per vocabulary entry)
+// — and a SIMD issues one VALU instruction per 4 cycles: a ~19 us VALU floor, above the HBM floor.  Persistent variants
+// (two LDS buffers with four lanes per row; one early-released buffer with the row copied to registers) overlapped the
+// loads but ran 33-41 us: four lanes per row double the instruction count, one lane per row makes a stage's arithmetic a
+// 4-6 us serial chain per wave behind which the block's next stage waits (tools/pred_bench.py has the harness).  Two
+// things found on the way apply here: `__syncthreads()` = vmcnt(0) + barrier drains every in-flight LDS-DMA, and LDS
+// reads placed under the `j < V` guards compile to one round trip per element (the row is now read unguarded, in one
+// batch: 29.7 -> 28.2 us).
 template <typename T, int VP, int graph, int step>
 __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
     predictor_step_rows_kernel(const T* __restrict__ ls, const int64_t* __restrict__ x,
@@ -645,15 +654,26 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
     const float cf = s_cf[r];
     const T* lrow = (const T*)smem + r * V;
     const float* urow = (const float*)s_u + r * Vu;
-    float e[VP], t[VP];
+    float e[VP], t[VP], un[VP];
+    // The row is read with all VP slots unconditionally and back to back (slots past the row's end read the next row or
+    // the slack behind the tile and are never consumed: every use below sits under a wave-uniform j < V guard).  Reads
+    // inside those guards compile to one LDS round trip per element: 2 V serial latencies per row.
+    {
+        T raw[VP];
+#pragma unroll
+        for (int j = 0; j < VP; ++j) raw[j] = lrow[j];
+#pragma unroll
+        for (int j = 0; j < VP; ++j) un[j] = urow[j];
+#pragma unroll
+        for (int j = 0; j < VP; ++j) e[j] = to_f32<T>(raw[j]);
+    }
     const bool euler = step == SEDD_STEP_EULER;
     const float invV = 1.0f / (float)V;
 #pragma unroll
     for (int j = 0; j < VP; ++j) {
-        e[j] = 0.f;
         t[j] = 0.f;
         if (j < V) {
-            const float s = expf(to_f32<T>(lrow[j]));
+            const float s = expf(e[j]);
             e[j] = s;
             const bool inc = euler ? j != xi : true;  // reverse_rate zeroes the diagonal before summing
             if (graph == SEDD_UNIFORM && euler) t[j] = inc ? invV * s : 0.f;
@@ -696,7 +716,7 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
                 const float stag = a_u * ssum + s / e_n;
                 p = stag * (j == xi ? tdiag : tval);
             }
-            const float v = gumbel_ratio_fast(p, urow[j]);
+            const float v = gumbel_ratio_fast(p, un[j]);
             if (j == 0) am.first(v);
             else am.push(v, j);
         }
@@ -723,7 +743,7 @@ extern "C" int sedd_predictor_step(int graph, int step, const void* logscore, in
                                            dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),         \
                                            dim3(RowsCfg<VP>::ROWS),                                                   \
                                            rows_lds(RowsCfg<VP>::ROWS, V * (int)sizeof(T)) +                          \
-                                               rows_lds(RowsCfg<VP>::ROWS, Vu * 4),                                   \
+                                               rows_lds(RowsCfg<VP>::ROWS, Vu * 4) + 256,                             \
                                            st, (const T*)logscore, x, coef, u, xnew, M, L, V))
 #define PRED_ROWS_ST(T, GR)                                                    \
     do {                                                                       \
