@@ -274,6 +274,21 @@ int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls,
                   const float* rot_cos, const float* rot_sin, sedd_stream_t stream);
 
+/* flash_attn_varlen_qkvpacked_func in its general, variable-length form (transformer.py:173-181 with `seqlens` given;
+ * spec: the vendored model/flash_attn_interface.py:1212-1275): the token axis of q / k / v / o ([total, H, d] views, token
+ * strides x_ls in elements) is cut into nseq segments [cu_seqlens[s], cu_seqlens[s+1]) (int32, nseq + 1 entries on the
+ * device, starting at 0) and attention runs inside each segment only (non-causal, scale d^-1/2, no dropout).
+ * max_len: upper bound of the segment lengths (the reference passes the padded row length); longer segments are cut.
+ * lse / delta fp32 [H, total].  Tokens outside every segment are not written.  Rotary is NOT fused here (positions are
+ * row positions, not segment positions: apply sedd_rotary_qkv before / its conjugate after). */
+int sedd_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* cu_seqlens,
+                         int nseq, int total, int max_len, int dtype, int H, int d, int64_t q_ls, int64_t kv_ls,
+                         int64_t o_ls, sedd_stream_t stream);
+int sedd_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, float* delta, const int32_t* cu_seqlens, int nseq, int total,
+                         int max_len, int dtype, int H, int d, int64_t q_ls, int64_t kv_ls, int64_t o_ls,
+                         sedd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------- optimiser / EMA
  * One pass over the flat fp32 parameter buffer: gradient clip coefficient (losses.py:65-66) -> AdamW
  * (losses.py:39-41; torch.optim.AdamW) -> EMA shadow update (model/ema.py:32-52) -> bf16 compute copy.

@@ -39,9 +39,22 @@ def _install_stubs():
         total, three, H, d = qkv.shape
         B = cu_seqlens.numel() - 1
         L = total // B
+        cu = [int(c) for c in cu_seqlens.tolist()]
         # a custom op: autocast only decides the dtype of what comes in, never the arithmetic inside (matters for g17,
         # where the caller's region runs under CPU autocast and einsum would otherwise be demoted to bf16)
         with torch.autocast("cpu", enabled=False):
+            if cu != list(range(0, (B + 1) * L, L)) or B * L != total:
+                # general variable-length form (flash_attn_interface.py:1212-1275): attention inside each segment
+                # [cu[s], cu[s+1]) of the packed token axis; tokens outside every segment stay zero
+                assert cu[0] == 0 and all(b >= a for a, b in zip(cu, cu[1:])) and cu[-1] <= total
+                assert max(b - a for a, b in zip(cu, cu[1:])) <= max_seqlen
+                out = torch.zeros(total, H, d, dtype=torch.float32)
+                for a, b in zip(cu, cu[1:]):
+                    if b > a:
+                        q, k, v = qkv[a:b].float().unbind(1)
+                        sc = torch.einsum("lhd,mhd->hlm", q, k) * (d ** -0.5)
+                        out[a:b] = torch.einsum("hlm,mhd->lhd", torch.softmax(sc, dim=-1), v)
+                return out.to(qkv.dtype)
             q, k, v = qkv.view(B, L, 3, H, d).float().unbind(2)
             s = torch.einsum("blhd,bmhd->bhlm", q, k) * (d ** -0.5)
             p = torch.softmax(s, dim=-1)
@@ -869,6 +882,37 @@ def g18_conditional_sampling():
     save("g18_conditional_sampling", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G19
+def g19_varlen_block():
+    """the flash-attn varlen hook of DDiTBlock.forward (transformer.py:173-179) with UNEQUAL segment lengths:
+    `seqlens` starts with 0 (cu_seqlens = seqlens.cumsum(-1) must start at 0 for flash-attn), segments of different
+    lengths that also straddle the padded rows (variable-length packing), forward + all gradients through the stub."""
+    torch.manual_seed(119)
+    out = {}
+    for tag, D, H, C, B, L, lens in (("a", 128, 2, 64, 2, 80, [0, 33, 47, 50, 30]),       # 4 segments over 2 x 80 tokens
+                                     ("b", 128, 4, 64, 3, 48, [0, 48, 7, 41, 20, 28])):   # incl. a 7-token segment
+        assert sum(lens) == B * L and max(lens) <= L
+        blk = ref_tf.DDiTBlock(D, H, C, dropout=0.0)
+        load_seeded(blk, seed=19, std=0.05)
+        blk.eval()
+        x = torch.randn(B, L, D, requires_grad=True)
+        c = torch.randn(B, C, requires_grad=True)
+        rot = ref_rotary.Rotary(D // H)
+        cos, sin = rot(x)
+        seqlens = torch.tensor(lens, dtype=torch.int32)
+        y = blk(x, (cos, sin), c, seqlens=seqlens)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        t = tag + "_"
+        out.update({t + "x": x, t + "c": c, t + "y": y, t + "w": w, t + "dx": x.grad, t + "dc": c.grad,
+                    t + "seqlens": seqlens, t + "dims": np.array([D, H, C, B, L])})
+        for n, p in blk.named_parameters():
+            out[t + "grad." + n] = p.grad
+        # the hook changes the result: same block, one segment per row
+        out[t + "y_rows"] = blk(x, (cos, sin), c)
+    save("g19_varlen_block", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -876,7 +920,8 @@ def main():
     for fn in (g1_noise, g2_sample_transition, g3_score_entropy, g4_graph_ops, g5_sample_categorical,
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
                g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule,
-               g16_cross_train_trajectory, g17_bf16_autocast, g18_conditional_sampling):
+               g16_cross_train_trajectory, g17_bf16_autocast, g18_conditional_sampling,
+               g19_varlen_block):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

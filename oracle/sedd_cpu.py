@@ -265,8 +265,22 @@ def softmax_attention(q, k, v, key_mask=None):
     return torch.einsum("bhlm,bmhd->blhd", p, v.float()).to(q.dtype)
 
 
-def ddit_block(sd, pre, x, c, n_heads, bf16=False):
-    """DDiTBlock.forward, flash variant (transformer.py:153-189), dropout = 0 / eval."""
+def varlen_attention(q, k, v, cu):
+    """flash_attn_varlen_qkvpacked_func in its general form (transformer.py:173-181): q / k / v [T, H, d] (the packed
+    token axis), cu = cumulative segment offsets starting at 0; exact softmax attention inside each segment; tokens
+    outside every segment are zero."""
+    out = torch.zeros_like(q, dtype=torch.float32)
+    d = q.shape[-1]
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            sc = torch.einsum("lhd,mhd->hlm", q[a:b].float(), k[a:b].float()) * (d ** -0.5)
+            out[a:b] = torch.einsum("hlm,mhd->lhd", torch.softmax(sc, -1), v[a:b].float())
+    return out.to(q.dtype)
+
+
+def ddit_block(sd, pre, x, c, n_heads, bf16=False, seqlens=None):
+    """DDiTBlock.forward, flash variant (transformer.py:153-189), dropout = 0 / eval.  seqlens: the varlen hook
+    (:173-179), cu_seqlens = seqlens.cumsum(-1) over the flattened (batch x sequence) token axis."""
     B, L, D = x.shape
     d = D // n_heads
     mod = _linear(c, sd[pre + "adaLN_modulation.weight"], sd[pre + "adaLN_modulation.bias"], bf16)
@@ -281,7 +295,12 @@ def ddit_block(sd, pre, x, c, n_heads, bf16=False):
     cos, sin = _cast(cos, bf16), _cast(sin, bf16)
     q, k, v = qkv.unbind(2)
     q, k = apply_rotary(q, cos, sin), apply_rotary(k, cos, sin)
-    o = softmax_attention(q, k, v).reshape(B, L, D)
+    if seqlens is None:
+        o = softmax_attention(q, k, v).reshape(B, L, D)
+    else:
+        cu = [int(t) for t in torch.as_tensor(seqlens).cumsum(-1).tolist()]
+        o = varlen_attention(q.reshape(B * L, n_heads, d), k.reshape(B * L, n_heads, d), v.reshape(B * L, n_heads, d),
+                             cu).reshape(B, L, D)
     x = x + g1 * _linear(o, sd[pre + "attn_out.weight"], None, bf16).float()
     h = layer_norm_w(x, sd[pre + "norm2.weight"]) * (1 + sc2) + sh2
     h = _linear(h, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], bf16)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "sedd_gemm_nn_dgelu": "plplpliipplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",
+    "sedd_attn_varlen_fwd": "pppppp" + "iiiiii" + "lll" + "p",
+    "sedd_attn_varlen_bwd": "pppppp" + "pppp" + "p" + "iiiiii" + "lll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
     "sedd_sumsq_clip": "plffppp",
     "sedd_ema_update": "ppflp",

@@ -264,7 +264,29 @@ struct AttnShape {
     float scale;
     const float* rot_cos;  // backward only: conjugate rotary on dQ / dK ([L, D/2] fp32 tables), or null
     const float* rot_sin;
+    // variable-length packing (flash_attn_varlen_qkvpacked_func's cu_seqlens, transformer.py:173-181): when cu != null the
+    // launch's "batch" index is a segment of the packed token axis: segment s = tokens [cu[s], cu[s+1]) of `total`, q / k /
+    // v / o addressed by token (x_ls), lse / delta laid out [H, total]; Lq = Lk = the launch's maximum segment length
+    const int* cu;
+    int total;
 };
+
+// Per-block view of a launch: base offsets of the block's batch element (or packed segment) and its lengths.
+struct AttnView { int64_t qo, ko, oo, lb; int Lq, Lk; };
+template <bool PLAIN>
+__device__ __forceinline__ AttnView attn_view(const AttnShape& sh, int b, int h) {
+    AttnView v{b * sh.q_bs, b * sh.kv_bs, b * sh.o_bs, ((int64_t)b * sh.H + h) * sh.Lq, sh.Lq, sh.Lk};
+    if constexpr (!PLAIN) {
+        if (sh.cu) {
+            int s0 = sh.cu[b], s1 = sh.cu[b + 1];
+            s0 = s0 < 0 ? 0 : (s0 > sh.total ? sh.total : s0);  // never address outside the packed buffer
+            s1 = s1 < s0 ? s0 : (s1 > sh.total ? sh.total : s1);
+            const int len = s1 - s0 < sh.Lq ? s1 - s0 : sh.Lq;  // (segments longer than the stated maximum are cut there)
+            v = AttnView{s0 * sh.q_ls, s0 * sh.kv_ls, s0 * sh.o_ls, (int64_t)h * sh.total + s0, len, len};
+        }
+    }
+    return v;
+}
 
 // ==================================================================================================== forward
 // PLAIN: no key mask and Lk a multiple of TILE — every score is valid (the training shapes); the general
@@ -280,11 +302,15 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
     const int nob = (sh.Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lin % nob, by = lin / nob;
     const int b = by / sh.H, h = by % sh.H;
-    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
-    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
-    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
+    const AttnView av = attn_view<PLAIN>(sh, b, h);
+    if (bx * OWN_PER_BLOCK >= av.Lq) return;  // (block-uniform: a packed segment shorter than the launch's maximum)
+    const T* qb = q + av.qo + (int64_t)h * D;
+    const T* kb = k + av.ko + (int64_t)h * D;
+    const T* vb = v + av.ko + (int64_t)h * D;
     const uint8_t* mb = !PLAIN && mask ? mask + (int64_t)b * sh.Lk : nullptr;
     const float sl2 = sh.scale * LOG2E;
+    sh.Lq = av.Lq;
+    sh.Lk = av.Lk;
 
     RowFrag<T, D> qf[2];
     int qrow[2];
@@ -371,10 +397,10 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         l += __shfl_xor(l, 32, 64);
         if (qrow[mt] < sh.Lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
-            T* orow = o + b * sh.o_bs + (int64_t)qrow[mt] * sh.o_ls + (int64_t)h * D;
+            T* orow = o + av.oo + (int64_t)qrow[mt] * sh.o_ls + (int64_t)h * D;
 #pragma unroll
             for (int dt = 0; dt < D / 16; ++dt) store4T<T>(orow + dt * 16 + 4 * g, acc[mt][dt] * inv);
-            if (g == 0) lse[((int64_t)b * sh.H + h) * sh.Lq + qrow[mt]] = (m[mt] + log2f(l)) * LN2;
+            if (g == 0) lse[av.lb + qrow[mt]] = (m[mt] + log2f(l)) * LN2;
         }
     }
 }
@@ -393,12 +419,16 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
     const int nob = (sh.Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lin % nob, by = lin / nob;
     const int b = by / sh.H, h = by % sh.H;
-    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
-    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
-    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
-    const T* dob = dout + b * sh.o_bs + (int64_t)h * D;
+    const AttnView av = attn_view<PLAIN>(sh, b, h);
+    if (bx * OWN_PER_BLOCK >= av.Lq) return;
+    const T* qb = q + av.qo + (int64_t)h * D;
+    const T* kb = k + av.ko + (int64_t)h * D;
+    const T* vb = v + av.ko + (int64_t)h * D;
+    const T* dob = dout + av.oo + (int64_t)h * D;
     const uint8_t* mb = !PLAIN && mask ? mask + (int64_t)b * sh.Lk : nullptr;
     const float sl2 = sh.scale * LOG2E;
+    sh.Lq = av.Lq;
+    sh.Lk = av.Lk;
 
     RowFrag<T, D> qf[2], dof[2];
     int qrow[2];
@@ -409,11 +439,11 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
         const bool ok = qrow[mt] < sh.Lq;
         qf[mt] = ok ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
         dof[mt] = ok ? load_rowfrag<T, D>(dob + (int64_t)qrow[mt] * sh.o_ls, g) : zero_rowfrag<T, D>();
-        const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (ok ? qrow[mt] : 0);
+        const int64_t si = av.lb + (ok ? qrow[mt] : 0);
         lq[mt] = ok ? lse[si] * LOG2E : 0.f;
         // delta = rowsum(dO * O) of this query (flash-attention backward's D), from the dO fragment already in
         // registers and the matching O fragment; also left in `delta` for the dK/dV kernel, which runs next
-        const RowFrag<T, D> of = ok ? load_rowfrag<T, D>(o + b * sh.o_bs + (int64_t)h * D + (int64_t)qrow[mt] * sh.o_ls, g)
+        const RowFrag<T, D> of = ok ? load_rowfrag<T, D>(o + av.oo + (int64_t)h * D + (int64_t)qrow[mt] * sh.o_ls, g)
                                     : zero_rowfrag<T, D>();
         float dsum = 0.f;
 #pragma unroll
@@ -482,7 +512,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
         if (qrow[mt] < sh.Lq) {
-            T* row = dq + b * sh.q_bs + (int64_t)qrow[mt] * sh.q_ls + (int64_t)h * D;
+            T* row = dq + av.qo + (int64_t)qrow[mt] * sh.q_ls + (int64_t)h * D;
             const int64_t ro = (int64_t)qrow[mt] * (D / 2);
             store_row_rot<T, D>(row, acc[mt], sh.scale, sh.rot_cos ? sh.rot_cos + ro : nullptr, sh.rot_sin + ro, g);
         }
@@ -503,11 +533,16 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
     const int nob = (sh.Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK, lin = attn_xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lin % nob, by = lin / nob;
     const int b = by / sh.H, h = by % sh.H;
-    const T* qb = q + b * sh.q_bs + (int64_t)h * D;
-    const T* kb = k + b * sh.kv_bs + (int64_t)h * D;
-    const T* vb = v + b * sh.kv_bs + (int64_t)h * D;
-    const T* dob = dout + b * sh.o_bs + (int64_t)h * D;
+    const AttnView av = attn_view<PLAIN>(sh, b, h);
+    if (bx * OWN_PER_BLOCK >= av.Lk) return;
+    const T* qb = q + av.qo + (int64_t)h * D;
+    const T* kb = k + av.ko + (int64_t)h * D;
+    const T* vb = v + av.ko + (int64_t)h * D;
+    const T* dob = dout + av.oo + (int64_t)h * D;
     const float sl2 = sh.scale * LOG2E;
+    const int64_t mask_b = (int64_t)b * sh.Lk;  // (the key mask is laid out with the launch's Lk)
+    sh.Lq = av.Lq;
+    sh.Lk = av.Lk;
 
     RowFrag<T, D> kf[2], vf[2];
     int krow[2];
@@ -518,7 +553,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
         const bool ok = krow[mt] < sh.Lk;
         kf[mt] = ok ? load_rowfrag<T, D>(kb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
         vf[mt] = ok ? load_rowfrag<T, D>(vb + (int64_t)krow[mt] * sh.kv_ls, g) : zero_rowfrag<T, D>();
-        kvalid[mt] = PLAIN || (ok && (!mask || mask[(int64_t)b * sh.Lk + krow[mt]]));
+        kvalid[mt] = PLAIN || (ok && (!mask || mask[mask_b + krow[mt]]));
     }
     f32x4 adk[2][D / 16], adv[2][D / 16];
 #pragma unroll
@@ -534,7 +569,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
         stage_load<T, D>(rdo, dob, sh.o_ls, (q0_), sh.Lq);                                       \
         if (threadIdx.x < TILE) {                                                                \
             const int qi = (q0_) + threadIdx.x;                                                  \
-            const int64_t si = ((int64_t)b * sh.H + h) * sh.Lq + (qi < sh.Lq ? qi : 0);          \
+            const int64_t si = av.lb + (qi < sh.Lq ? qi : 0);                                    \
             r_lse = qi < sh.Lq ? lse[si] * LOG2E : INFINITY;                                     \
             r_del = qi < sh.Lq ? delta[si] : 0.f;                                                \
         }                                                                                        \
@@ -586,7 +621,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
         if (krow[mt] < sh.Lk) {
-            const int64_t off = b * sh.kv_bs + (int64_t)krow[mt] * sh.kv_ls + (int64_t)h * D;
+            const int64_t off = av.ko + (int64_t)krow[mt] * sh.kv_ls + (int64_t)h * D;
             const int64_t ro = (int64_t)krow[mt] * (D / 2);
             store_row_rot<T, D>(dk + off, adk[mt], sh.scale, sh.rot_cos ? sh.rot_cos + ro : nullptr, sh.rot_sin + ro, g);
 #pragma unroll
@@ -626,17 +661,16 @@ static int check_attn(const char* nm, int dtype, int B, int H, int Lq, int Lk, i
         }                                                                                     \
     } while (0)
 
-extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
-                             const uint8_t* key_mask, int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs,
-                             int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls,
-                             sedd_stream_t stream) {
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* key_mask,
+                         int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
+                         int64_t kv_ls, int64_t o_bs, int64_t o_ls, const int* cu, int total, sedd_stream_t stream) {
     int rc = check_attn("attn_fwd", dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls);
     if (rc) return rc;
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
-    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr};
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr, cu, total};
     const dim3 grid((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
-    const bool plain = !key_mask && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
+    const bool plain = !key_mask && !cu && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
 #define FWD_LAUNCH(PL) hipLaunchKernelGGL((attn_fwd_kernel<T, D, PL>), grid, dim3(256), 0, (hipStream_t)stream,       \
                                           (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, key_mask, sh)
     DISPATCH_ATTN(dtype, d, {
@@ -650,22 +684,22 @@ extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* 
     return SEDD_OK;
 }
 
-extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                             const float* lse, const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta,
-                             int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
-                             int64_t kv_ls, int64_t o_bs, int64_t o_ls, const float* rot_cos, const float* rot_sin,
-                             sedd_stream_t stream) {
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                         const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta, int dtype, int B, int H,
+                         int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs,
+                         int64_t o_ls, const float* rot_cos, const float* rot_sin, const int* cu, int total,
+                         sedd_stream_t stream) {
     int rc = check_attn("attn_bwd", dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls);
     if (rc) return rc;
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "attn_bwd: null pointer");
     SEDD_CHECK_ARG((rot_cos == nullptr) == (rot_sin == nullptr), "attn_bwd: rot_cos and rot_sin go together");
     SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
-    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin};
+    AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin, cu, total};
     hipStream_t st = (hipStream_t)stream;
     const dim3 gq((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H)),
         gk((unsigned)((int64_t)((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
-    const bool plain_q = !key_mask && Lk % TILE == 0, plain_k = !key_mask && Lk % OWN_PER_BLOCK == 0;
+    const bool plain_q = !key_mask && !cu && Lk % TILE == 0, plain_k = !key_mask && !cu && Lk % OWN_PER_BLOCK == 0;
 #define DQ_LAUNCH(PL) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, PL>), gq, dim3(256), 0, st, (const T*)q,           \
                                          (const T*)k, (const T*)v, (const T*)o, (const T*)dout, lse, delta, key_mask,  \
                                          (T*)dq, sh)
@@ -687,4 +721,46 @@ extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const 
 #undef DKV_LAUNCH
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
+}
+
+extern "C" int sedd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                             const uint8_t* key_mask, int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs,
+                             int64_t q_ls, int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls,
+                             sedd_stream_t stream) {
+    return attn_fwd_impl(q, k, v, o, lse, key_mask, dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, nullptr, 0,
+                         stream);
+}
+
+extern "C" int sedd_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                             const float* lse, const uint8_t* key_mask, void* dq, void* dk, void* dv, float* delta,
+                             int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls, int64_t kv_bs,
+                             int64_t kv_ls, int64_t o_bs, int64_t o_ls, const float* rot_cos, const float* rot_sin,
+                             sedd_stream_t stream) {
+    return attn_bwd_impl(q, k, v, o, dout, lse, key_mask, dq, dk, dv, delta, dtype, B, H, Lq, Lk, d, q_bs, q_ls, kv_bs, kv_ls,
+                         o_bs, o_ls, rot_cos, rot_sin, nullptr, 0, stream);
+}
+
+// ---- variable-length packing: flash_attn_varlen_qkvpacked_func's general form (transformer.py:173-181)
+static int check_varlen(const char* nm, const int* cu, int nseq, int total, int max_len) {
+    SEDD_CHECK_ARG(nseq >= 0 && total >= 0 && max_len > 0, "%s: bad sizes nseq=%d total=%d max_len=%d", nm, nseq, total,
+                   max_len);
+    SEDD_CHECK_ARG(nseq == 0 || cu, "%s: cu_seqlens is null", nm);
+    return SEDD_OK;
+}
+extern "C" int sedd_attn_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                                    const int32_t* cu_seqlens, int nseq, int total, int max_len, int dtype, int H, int d,
+                                    int64_t q_ls, int64_t kv_ls, int64_t o_ls, sedd_stream_t stream) {
+    int rc = check_varlen("attn_varlen_fwd", cu_seqlens, nseq, total, max_len);
+    if (rc) return rc;
+    return attn_fwd_impl(q, k, v, o, lse, nullptr, dtype, nseq, H, max_len, max_len, d, 0, q_ls, 0, kv_ls, 0, o_ls,
+                         cu_seqlens, total, stream);
+}
+extern "C" int sedd_attn_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                    const float* lse, void* dq, void* dk, void* dv, float* delta,
+                                    const int32_t* cu_seqlens, int nseq, int total, int max_len, int dtype, int H, int d,
+                                    int64_t q_ls, int64_t kv_ls, int64_t o_ls, sedd_stream_t stream) {
+    int rc = check_varlen("attn_varlen_bwd", cu_seqlens, nseq, total, max_len);
+    if (rc) return rc;
+    return attn_bwd_impl(q, k, v, o, dout, lse, nullptr, dq, dk, dv, delta, dtype, nseq, H, max_len, max_len, d, 0, q_ls, 0,
+                         kv_ls, 0, o_ls, nullptr, nullptr, cu_seqlens, total, stream);
 }

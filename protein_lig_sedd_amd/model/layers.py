@@ -165,7 +165,7 @@ BLOCK_PARAMS = ("norm1.weight", "attn_qkv.weight", "attn_out.weight", "norm2.wei
                 "mlp.2.weight", "mlp.2.bias", "adaLN_modulation.weight", "adaLN_modulation.bias")
 
 
-def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
+def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens=None):
     """DDiTBlock.forward (model/transformer.py:153-189).  x fp32 [B, L, D]; c fp32 [B, C]; P: dict of the block's
     parameters by reference name; cos/sin compact rotary tables.  Returns x_out fp32 and (if save) the saved state."""
     B, L, D = x.shape
@@ -180,7 +180,10 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
     else:
         qkv = linear_fwd(h1.view(M, D), P["attn_qkv.weight"]).view(B, L, 3, H, d)
         ops.rotary_qkv_(qkv, cos, sin)
-    o, lse = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+    if cu_seqlens is None:
+        o, lse = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+    else:  # variable-length packing: attention inside the segments of the flattened token axis (transformer.py:173-181)
+        o, lse = ops.attn_varlen_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], cu_seqlens, L)
     a = linear_fwd(o.view(M, D), P["attn_out.weight"]).view(B, L, D)
     inv = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     keep1 = dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
@@ -200,7 +203,8 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save):
     st = None
     if save:
         st = dict(x=x, c_c=c_c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
-                  x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, g=g, y=y, keep2=keep2, inv=inv, cos=cos, sin=sin)
+                  x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, g=g, y=y, keep2=keep2, inv=inv, cos=cos, sin=sin,
+                  cu=cu_seqlens)
     return x2, st
 
 
@@ -234,8 +238,14 @@ def ddit_block_backward(dx2, st, P, n_heads):
     do, grads["attn_out.weight"], _ = linear_bwd(st["o"].view(M, D), da, P["attn_out.weight"])
     qkv = st["qkv"]
     dqkv = torch.empty_like(qkv)
-    ops.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], st["o"], do.view(B, L, H, d), st["lse"], dqkv[:, :, 0],
-                 dqkv[:, :, 1], dqkv[:, :, 2], rotary=(st["cos"], st["sin"]))  # rotary's gradient fused into the stores
+    if st.get("cu") is None:
+        ops.attn_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], st["o"], do.view(B, L, H, d), st["lse"], dqkv[:, :, 0],
+                     dqkv[:, :, 1], dqkv[:, :, 2], rotary=(st["cos"], st["sin"]))  # rotary's gradient fused into the stores
+    else:
+        dqkv.zero_()  # (tokens outside every segment receive no gradient)
+        ops.attn_varlen_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], st["o"], do.view(B, L, H, d), st["lse"], dqkv[:, :, 0],
+                            dqkv[:, :, 1], dqkv[:, :, 2], st["cu"], L)
+        ops.rotary_qkv_(dqkv, st["cos"], st["sin"], conj=True)  # positions are row positions: not fused into the stores
     dh1, grads["attn_qkv.weight"], _ = linear_bwd(st["h1"].view(M, D), dqkv.view(M, 3 * D), P["attn_qkv.weight"])
     dw1, grads["norm1.weight"] = _vec_sink(P["norm1.weight"], D)
     ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],

@@ -116,10 +116,11 @@ class EmbeddingLayer(nn.Module):
 
 class _DDiTBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, blk, cos, sin, save, *params):
+    def forward(ctx, x, c, blk, cos, sin, save, cu, *params):
         P = dict(zip(Lyr.BLOCK_PARAMS, params))
         p = blk.dropout if blk.training else 0.0
-        out, st = Lyr.ddit_block_forward(x.contiguous(), c.contiguous(), P, blk.n_heads, cos, sin, p, blk.compute_dtype, save)
+        out, st = Lyr.ddit_block_forward(x.contiguous(), c.contiguous(), P, blk.n_heads, cos, sin, p, blk.compute_dtype, save,
+                                         cu_seqlens=cu)
         ctx.st, ctx.P, ctx.n_heads, ctx.blk = st, P, blk.n_heads, blk
         return out
 
@@ -130,7 +131,7 @@ class _DDiTBlockFn(torch.autograd.Function):
         cb = getattr(ctx.blk, "_on_grads_ready", None)  # trainer hook: this block's gradient bucket is complete
         if cb is not None:
             cb()
-        return (dx, dc, None, None, None, None) + _ret(grads, Lyr.BLOCK_PARAMS)
+        return (dx, dc, None, None, None, None, None) + _ret(grads, Lyr.BLOCK_PARAMS)
 
 
 class DDiTBlock(nn.Module):
@@ -167,11 +168,14 @@ class DDiTBlock(nn.Module):
         return self._rot[1], self._rot[2]
 
     def forward(self, x, rotary_cos_sin, c, seqlens=None):
-        if seqlens is not None:
-            raise NotImplementedError("variable-length packing (seqlens) is not exercised by the reference trainers")
+        """seqlens (transformer.py:173-179): the flash-attn varlen hook — `cu_seqlens = seqlens.cumsum(-1)` cuts the
+        flattened (batch x sequence) token axis into segments and attention runs inside each segment (variable-length
+        packing); as in the reference the caller's `seqlens` therefore starts with 0 and sums to batch x seq_len, and the
+        padded row length is the stated maximum segment length.  None: one segment per row."""
         cos, sin = self._tables(rotary_cos_sin)
         P = _params(self, Lyr.BLOCK_PARAMS)
-        return _DDiTBlockFn.apply(x, c, self, cos, sin, torch.is_grad_enabled(), *[P[n] for n in Lyr.BLOCK_PARAMS])
+        cu = None if seqlens is None else seqlens.cumsum(-1).to(torch.int32).contiguous()
+        return _DDiTBlockFn.apply(x, c, self, cos, sin, torch.is_grad_enabled(), cu, *[P[n] for n in Lyr.BLOCK_PARAMS])
 
 
 class _FinalLayerFn(torch.autograd.Function):

@@ -99,8 +99,7 @@ class DDiTBlock(nn.Module):
         self.seq_axis_attention = seq_axis_attention  # False = reference as written (quirk Q1: batch-axis attention)
 
     def forward(self, x, rotary_cos_sin, c, other_track=None, other_mask=None, seqlens=None):
-        if seqlens is not None:
-            raise NotImplementedError("variable-length packing (seqlens) is not exercised by the reference trainers")
+        # (seqlens is accepted and unused, as in the reference's cross block, :279-320: its attention is nn.MultiheadAttention)
         cos, sin = rotary_cos_sin
         comp = getattr(cos, "_sedd_compact", None) or Lyr.compact_rotary(cos, sin)
         use_cross = self.enable_cross_attention and other_track is not None

@@ -658,6 +658,58 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, key_mask=None, rotary=None):
                                   o.stride(1), _p(rc), _p(rs), _stream()), "sedd_attn_bwd")
 
 
+def _packed_token_stride(t, name):
+    """t: [B, L, H, d] view whose flattened (B L) token axis has ONE stride (batch stride = L x token stride)."""
+    B, L, H, d = t.shape
+    if t.stride(3) != 1 or t.stride(2) != d or (B > 1 and t.stride(0) != L * t.stride(1)):
+        raise ValueError(f"{name}: need layout [B, L, H, d] with contiguous (H, d) and a uniform token stride")
+    return t.stride(1)
+
+
+def _check_cu(cu):
+    if cu.dtype != torch.int32 or cu.dim() != 1 or cu.numel() < 1 or not cu.is_contiguous() or not cu.is_cuda:
+        raise ValueError("cu_seqlens must be a contiguous int32 device vector (nseq + 1 entries, starting at 0)")
+
+
+def attn_varlen_fwd(q, k, v, cu_seqlens, max_len):
+    """flash_attn_varlen_qkvpacked_func's general form: q / k / v [B, L, H, d] views (slots of a packed qkv); the flattened
+    (B L) token axis is cut into segments [cu[s], cu[s+1]); attention inside each segment.
+    -> (o [B, L, H, d] contiguous, zero outside the segments; lse fp32 [H, B L])."""
+    _cuda(q, k, v, cu_seqlens)
+    _check_cu(cu_seqlens)
+    B, L, H, d = q.shape
+    T = B * L
+    qs, ks = _packed_token_stride(q, "attn_varlen_fwd q"), _packed_token_stride(k, "attn_varlen_fwd k")
+    if _packed_token_stride(v, "attn_varlen_fwd v") != ks:
+        raise ValueError("k and v must share strides")
+    o = torch.zeros(B, L, H, d, dtype=q.dtype, device=q.device)
+    lse = torch.zeros(H, T, dtype=torch.float32, device=q.device)
+    with _Timed("attn_fwd", 4.0 * T * H * max_len * d):
+        check(lib().sedd_attn_varlen_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(cu_seqlens), cu_seqlens.numel() - 1, T,
+                                         int(max_len), _dt(q), H, d, qs, ks, o.stride(1), _stream()), "sedd_attn_varlen_fwd")
+    return o, lse
+
+
+def attn_varlen_bwd(q, k, v, o, dout, lse, dq, dk, dv, cu_seqlens, max_len):
+    """dq / dk / dv: preallocated (zeroed) views with the strides of q / k / v; gradients w.r.t. the q / k the kernel saw
+    (post-rotary)."""
+    _check_cu(cu_seqlens)
+    B, L, H, d = q.shape
+    T = B * L
+    qs, ks = _packed_token_stride(q, "attn_varlen_bwd q"), _packed_token_stride(k, "attn_varlen_bwd k")
+    if (_packed_token_stride(dq, "dq") != qs or _packed_token_stride(dk, "dk") != ks or _packed_token_stride(dv, "dv") != ks
+            or _packed_token_stride(v, "v") != ks):
+        raise ValueError("gradient views must share the strides of their primal tensors")
+    os_ = _packed_token_stride(o, "o")
+    if _packed_token_stride(dout, "dout") != os_:
+        raise ValueError("dout must be laid out like o")
+    delta = torch.zeros(H, T, dtype=torch.float32, device=q.device)
+    with _Timed("attn_bwd", 10.0 * T * H * max_len * d):
+        check(lib().sedd_attn_varlen_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(dq), _p(dk), _p(dv), _p(delta),
+                                         _p(cu_seqlens), cu_seqlens.numel() - 1, T, int(max_len), _dt(q), H, d, qs, ks,
+                                         os_, _stream()), "sedd_attn_varlen_bwd")
+
+
 # ------------------------------------------------------------------------------------------ optimiser
 def sumsq_clip(g, gscale=1.0, max_norm=0.0, ws=None, out=None):
     if ws is None:

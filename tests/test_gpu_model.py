@@ -246,3 +246,86 @@ def test_g17_bf16_path_vs_the_reference_under_autocast(golden):
     for k, p in model.named_parameters():
         ref = g["mini_grad." + k]
         assert rel_err(p.grad, ref) < 3e-2, f"{k}: {rel_err(p.grad, ref):.3e}"
+
+
+def _varlen_ref(q, k, v, cu):
+    out = torch.zeros_like(q, dtype=torch.float32)
+    d = q.shape[-1]
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            sc = torch.einsum("lhd,mhd->hlm", q[a:b].float(), k[a:b].float()) * (d ** -0.5)
+            out[a:b] = torch.einsum("hlm,mhd->lhd", torch.softmax(sc, -1), v[a:b].float())
+    return out
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("d", [32, 64, 96])
+def test_attn_varlen_kernels(dtype, tol, d):
+    """sedd_attn_varlen_fwd / _bwd on a packed qkv [B, L, 3, H, d] against exact per-segment softmax attention (fp32
+    autograd): ragged segments that cross the 64-key tiles and the 128-row blocks, a 1-token and an EMPTY segment, a
+    segment as long as the stated maximum, and a tail of tokens that belongs to no segment (must stay zero)."""
+    from protein_lig_sedd_amd import ops
+    torch.manual_seed(d)
+    B, L, H = 3, 160, 2
+    T = B * L
+    lens = [0, 160, 1, 0, 131, 64, 97]            # sums to 453 < T = 480: 27 tokens outside every segment
+    cu_list = torch.tensor(lens).cumsum(0).tolist()
+    cu = torch.tensor(cu_list, dtype=torch.int32, device=DEV)
+    qkv32 = (torch.randn(B, L, 3, H, d) * 0.7)
+    qkv = qkv32.to(DEV).to(dtype)
+    ref_in = qkv.float().cpu().reshape(T, 3, H, d).requires_grad_(True)
+    ref = _varlen_ref(ref_in[:, 0], ref_in[:, 1], ref_in[:, 2], cu_list)
+    w = torch.randn(T, H, d)
+    (ref * w).sum().backward()
+    o, lse = ops.attn_varlen_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], cu, L)
+    assert o.shape == (B, L, H, d) and lse.shape == (H, T)
+    assert rel_err(o.float().reshape(T, H, d), ref.detach()) < tol
+    assert float(o.reshape(T, H, d)[cu_list[-1]:].abs().max()) == 0.0
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_varlen_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, w.to(DEV).to(dtype).view(B, L, H, d), lse,
+                        dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], cu, L)
+    got = dqkv.float().cpu().reshape(T, 3, H, d)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        assert rel_err(got[:, i], ref_in.grad[:, i]) < (tol if dtype == torch.float32 else 3e-2), nm
+    assert float(got[cu_list[-1]:].abs().max()) == 0.0
+    # equal-length segments = the fixed-length kernel
+    cu_eq = torch.arange(0, (B + 1) * L, L, dtype=torch.int32, device=DEV)
+    o2, _ = ops.attn_varlen_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], cu_eq, L)
+    o3, _ = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+    assert rel_err(o2.float(), o3.float()) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g19_ddit_block_varlen(golden, tag):
+    """DDiTBlock.forward(seqlens=...) — the flash-attn varlen hook (transformer.py:173-179), SURVEY 8(f4) — against the
+    reference block run with unequal segment lengths (golden g19): fp32 forward + all gradients at 1e-4, and the bf16
+    path against the oracle at 2e-2."""
+    from protein_lig_sedd_amd.model.transformer import DDiTBlock
+    from protein_lig_sedd_amd.model.rotary import Rotary
+    g = golden("g19_varlen_block")
+    t = tag + "_"
+    D, H, C, B, L = g[t + "dims"].tolist()
+    sd = seeded_state_dict(_block_shapes(D, C), seed=19, std=0.05)
+    blk = DDiTBlock(D, H, C, dropout=0.0, compute_dtype=torch.float32).to(DEV)
+    load_sd(blk, sd)
+    x = g[t + "x"].to(DEV).requires_grad_(True)
+    c = g[t + "c"].to(DEV).requires_grad_(True)
+    seqlens = g[t + "seqlens"].to(DEV)
+    rot = Rotary(D // H).to(DEV)
+    y = blk(x, rot(x), c, seqlens=seqlens)
+    assert rel_err(y, g[t + "y"]) < 1e-5
+    assert_close(y, g[t + "y"], 1e-4, 5e-5, "y")
+    (y * g[t + "w"].to(DEV)).sum().backward()
+    assert_close(x.grad, g[t + "dx"], 1e-4, 5e-5, "dx")
+    assert_close(c.grad, g[t + "dc"], 1e-4, 4e-4, "dc")
+    for k, p in blk.named_parameters():
+        ref = g[t + "grad." + k]
+        assert rel_err(p.grad, ref) < 1e-4, k
+    with torch.no_grad():
+        assert_close(blk(x, rot(x), c), g[t + "y_rows"], 1e-4, 5e-5, "seqlens=None")
+    blk16 = DDiTBlock(D, H, C, dropout=0.0, compute_dtype=torch.bfloat16).to(DEV)
+    load_sd(blk16, sd)
+    with torch.no_grad():
+        y16 = blk16(x, rot(x), c, seqlens=seqlens)
+        ref16 = O.ddit_block(sd, "", g[t + "x"], g[t + "c"], H, bf16=True, seqlens=g[t + "seqlens"])
+    assert rel_err(y16 - x.detach(), ref16.float() - g[t + "x"]) < 2e-2

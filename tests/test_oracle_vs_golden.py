@@ -402,3 +402,24 @@ def test_g18_conditional_sampling(golden):
                 else:
                     x = O.denoise_step(graph, logits, x, sg[0], g[tag + "_u_denoise"])
         assert torch.equal(x, g[tag + "_out"]), tag
+
+
+def test_g19_varlen_block(golden):
+    """The oracle's variable-length attention (the flash-attn varlen hook, transformer.py:173-179) against the reference
+    block run with unequal `seqlens` through the generator's stub: forward and every gradient."""
+    g = golden("g19_varlen_block")
+    for tag in ("a", "b"):
+        t = tag + "_"
+        D, H, C, B, L = g[t + "dims"].tolist()
+        sd = {k: v.clone().requires_grad_(True) for k, v in seeded_state_dict(_block_shapes(D, C), seed=19, std=0.05).items()}
+        x, c = g[t + "x"].clone().requires_grad_(True), g[t + "c"].clone().requires_grad_(True)
+        y = O.ddit_block(sd, "", x, c, H, seqlens=g[t + "seqlens"])
+        assert_close(y, g[t + "y"], 1e-5, 1e-5, tag + " y")
+        (y * g[t + "w"]).sum().backward()
+        assert_close(x.grad, g[t + "dx"], 1e-4, 1e-5, tag + " dx")
+        assert_close(c.grad, g[t + "dc"], 1e-4, 1e-4, tag + " dc")
+        for k, v in sd.items():
+            assert_close(v.grad, g[t + "grad." + k], 1e-4, 1e-4, tag + " " + k)
+        with torch.no_grad():  # the hook matters: one-segment-per-row attention gives a different result
+            assert float((O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g[t + "x"], g[t + "c"], H) - g[t + "y"]).abs().max()) > 1e-3
+            assert_close(O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g[t + "x"], g[t + "c"], H), g[t + "y_rows"], 1e-5, 1e-5)
