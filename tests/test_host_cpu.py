@@ -210,3 +210,34 @@ def test_g1_product_noise_schedules(golden):
     assert len(list(noise_lib.get_noise(NS(noise=cases[3][1])).parameters())) == 0            # Cosine has none
     with pytest.raises(ValueError):
         noise_lib.get_noise(NS(noise=NS(type="sqrt")))
+
+
+def test_data_path_helpers():
+    """SURVEY 8(f4) host data path: fixed-pad batches (data/tokenize.py:14,25), variable-length packing in the form the
+    varlen hook takes (model/transformer.py:173-179), and DistributedSampler's shards (data/process_full_plinder.py:396-398)."""
+    from torch.utils.data import DistributedSampler
+    from protein_lig_sedd_amd import data
+    ids, mask = data.pad_to_fixed([[5, 6, 7], list(range(10)), []], 8, pad_id=1)
+    assert ids.tolist() == [[5, 6, 7, 1, 1, 1, 1, 1], list(range(8)), [1] * 8]
+    assert mask.sum(1).tolist() == [3, 8, 0] and ids.dtype == torch.int64
+    with pytest.raises(ValueError):
+        data.pad_to_fixed([list(range(10))], 8, 1, truncation=False)
+    seqs = [[1] * 5, [2] * 7, [3] * 3, [4] * 8, [5] * 2]
+    tok, seqlens = data.pack_sequences(seqs, 10, pad_id=0)
+    assert int(seqlens[0]) == 0 and int(seqlens.sum()) == tok.numel() and seqlens.dtype == torch.int32
+    cu = seqlens.cumsum(-1).tolist()
+    flat = tok.reshape(-1).tolist()
+    segs = [flat[a:b] for a, b in zip(cu[:-1], cu[1:])]
+    data_segs = [s for s in segs if s and s[0] != 0]
+    assert sorted(map(tuple, data_segs)) == sorted(map(tuple, seqs))      # every sequence is exactly one segment
+    assert all(len(set(s)) == 1 for s in segs if s)                       # padding never shares a segment with data
+    assert tok.shape[0] == 3                                              # 25 tokens first-fit into rows of 10
+    for n, world in ((10, 2), (11, 4), (3, 8), (64, 8)):
+        for shuffle in (False, True):
+            for drop_last in (False, True):
+                for rank in range(world):
+                    ref = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=shuffle, seed=7,
+                                             drop_last=drop_last)
+                    ref.set_epoch(3)
+                    got = data.distributed_indices(n, rank, world, shuffle=shuffle, seed=7, epoch=3, drop_last=drop_last)
+                    assert got == list(ref), (n, world, shuffle, drop_last, rank)
