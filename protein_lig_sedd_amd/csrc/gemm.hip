@@ -385,7 +385,13 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 // ROT = true (sedd_gemm_nt_rotary): the output is a packed qkv [M, 3, H, 64] and the NeoX rotary rotation of
 //   rotary.py:42-51 is applied to its q and k columns in the epilogue — a wave's 64 output columns are exactly one
 //   head, and the pair (j, j + 32) sits in fragments n and n + 2 of the same lane.
-struct RotArgs { const float* cos; const float* sin; int L; int64_t cols; };  // tables [L, 32]; cols = 2 * H * 64
+struct RotArgs { const float* cos; const float* sin; int L; int64_t cols; };
+#ifdef GEMM_CLOCK_STAMP
+__device__ uint64_t sedd_gemm_stamps[2048];
+extern "C" int sedd_debug_gemm_stamps(uint64_t* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sedd_gemm_stamps), sizeof(uint64_t) * 2048) == hipSuccess ? 0 : -3;
+}
+#endif  // tables [L, 32]; cols = 2 * H * 64
 template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false, bool ROT = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
@@ -531,6 +537,9 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         __builtin_amdgcn_s_setprio(0);                                                                               \
     } while (0)
 
+#ifdef GEMM_CLOCK_STAMP  // diagnostic build (tools/gemm_clock.py): shader clock held under load = d(memtime) / d(memrealtime) x 100 MHz
+    const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // persistent over output tiles: the next tile's first K tiles are in flight while this tile's results leave
     int tile = splitk > 1 ? work % ntiles : (int)blockIdx.x;
     if (tile >= ntiles) return;
@@ -562,11 +571,21 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         const int rem = nkt - 2 - kt;
                         wait_tiles<LPT>(rem < NST - 3 ? rem : NST - 3);  // K tile kt+1 has landed (this wave's share)
                         __builtin_amdgcn_s_barrier();  // ... every wave's share; the stage of tile kt-1 is consumed
+#ifndef GEMM_NO_STAGGER
+                        // the two waves of a SIMD run the same program in step: if both issue their LDS-DMA pieces right
+                        // behind the barrier, neither feeds the matrix pipe meanwhile.  The second half of the block
+                        // issues after its second MFMA group instead (same vmcnt bookkeeping: still before the next wait)
+                        if (wave < NW / 2 && kt + NST - 1 < nkt) BIG_STAGE((s + NST - 1) % NST, kt + NST - 1);
+#else
                         if (kt + NST - 1 < nkt) BIG_STAGE((s + NST - 1) % NST, kt + NST - 1);
+#endif
                         BIG_READ_A(a_lo, (s + 1) % NST, 0);
                         BIG_READ_B((s + 1) & 1, (s + 1) % NST);
                     }
                     BIG_MMA(a_hi, TMH, s & 1);
+#ifndef GEMM_NO_STAGGER
+                    if (wave >= NW / 2 && kt + 1 < nkt && kt + NST - 1 < nkt) BIG_STAGE((s + NST - 1) % NST, kt + NST - 1);
+#endif
                 }
             }
         }
@@ -791,6 +810,12 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         if (next >= ntiles) break;
         tile = next;
     }
+#ifdef GEMM_CLOCK_STAMP
+    if (tid == 0 && blockIdx.x < 1024) {
+        sedd_gemm_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        sedd_gemm_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
 #undef BIG_MMA
 #undef BIG_READ_B
 #undef BIG_READ_A

@@ -12,7 +12,7 @@ for l in libs:
     h.sedd_gemm_nt.restype = ctypes.c_int
     handles.append(h)
 P, L, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
-shapes = [(32768, 2304, 768), (32768, 768, 768), (32768, 3072, 768), (32768, 768, 3072), (131072, 2304, 768), (131072, 768, 768)]
+shapes = [(4096, 4096, 4096), (32768, 2304, 768), (32768, 768, 768), (32768, 3072, 768), (32768, 768, 3072), (131072, 2304, 768), (131072, 768, 768)]
 for M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16(); B = torch.randn(N, K, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
