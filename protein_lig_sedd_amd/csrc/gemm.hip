@@ -385,13 +385,26 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_addr) {
 // ROT = true (sedd_gemm_nt_rotary): the output is a packed qkv [M, 3, H, 64] and the NeoX rotary rotation of
 //   rotary.py:42-51 is applied to its q and k columns in the epilogue — a wave's 64 output columns are exactly one
 //   head, and the pair (j, j + 32) sits in fragments n and n + 2 of the same lane.
-struct RotArgs { const float* cos; const float* sin; int L; int64_t cols; };
+struct RotArgs { const float* cos; const float* sin; int L; int64_t cols; };  // tables [L, 32]; cols = 2 * H * 64
 #ifdef GEMM_CLOCK_STAMP
 __device__ uint64_t sedd_gemm_stamps[2048];
 extern "C" int sedd_debug_gemm_stamps(uint64_t* host_dst) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sedd_gemm_stamps), sizeof(uint64_t) * 2048) == hipSuccess ? 0 : -3;
 }
-#endif  // tables [L, 32]; cols = 2 * H * 64
+#endif
+#ifdef GEMM_PHASE_STAMP  // diagnostic build (tools/gemm_phase.py): per block and tile round, 100 MHz stamps at loop start /
+__device__ uint64_t sedd_gemm_phase[512 * 8 * 3];  // main loop end / epilogue issued
+extern "C" int sedd_debug_gemm_phase(uint64_t* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sedd_gemm_phase), sizeof(sedd_gemm_phase)) == hipSuccess ? 0 : -3;
+}
+#define PHASE_STAMP(k)                                                                                               \
+    do {                                                                                                             \
+        if (tid == 0 && blockIdx.x < 512 && phase_round < 8)                                                         \
+            sedd_gemm_phase[(blockIdx.x * 8 + phase_round) * 3 + (k)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
+#else
+#define PHASE_STAMP(k) do {} while (0)
+#endif
 template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false, bool ROT = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
@@ -543,9 +556,19 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     // persistent over output tiles: the next tile's first K tiles are in flight while this tile's results leave
     int tile = splitk > 1 ? work % ntiles : (int)blockIdx.x;
     if (tile >= ntiles) return;
+#ifdef GEMM_PHASE_STAMP
+    int phase_round = 0;
+#ifdef GEMM_SKEW_TICKS  // experiment: half of the blocks start late, so epilogues and main loops of neighbours overlap
+    if (NW == 4 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x >> 3) & 1) {
+        const uint64_t t0_ = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0_ < GEMM_SKEW_TICKS) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+#endif
     BIG_TILE_SETUP(tile);
     BIG_PROLOGUE();
     while (true) {
+        PHASE_STAMP(0);
         f32x4 acc[TM][4];
 #pragma unroll
         for (int m = 0; m < TM; ++m)
@@ -560,6 +583,12 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         __builtin_amdgcn_s_barrier();
         BIG_READ_A(a_lo, 0, 0);
         BIG_READ_B(0, 0);
+        // (Tried and measured slower, same-device A/B on the cfg-2 shapes and 4096^3, results bit-identical: straight-line
+        // steps with literal ring positions -2..-4 %; the next tile's fragment reads issued unconditionally so that the
+        // second MFMA group's lgkmcnt need not cover them +2 % on top of that, still below this form; m0 as wave base +
+        // literal with the K advance in the DMA's immediate offset -4 % — and note the instruction adds that immediate
+        // to the LDS address as well as to the global one.  With all-zero operands the same binary runs 20 % faster
+        // (1.26 -> 1.52 PFLOP/s at 4096^3): under random data the chip holds ~1.94 GHz, not 2.4, in this kernel.)
         for (int kt0 = 0; kt0 < nkt; kt0 += UNR) {
 #pragma unroll
             for (int s = 0; s < UNR; ++s) {
@@ -593,6 +622,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         const int next = splitk > 1 ? ntiles : tile + (int)gridDim.x;
         // the ring is free once every wave has issued its last MFMAs: start the next tile's loads under the epilogue
         __builtin_amdgcn_s_barrier();
+        PHASE_STAMP(1);
         if (next < ntiles) {
             BIG_TILE_SETUP(next);
             BIG_PROLOGUE();
@@ -807,6 +837,10 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #undef ROT_LOAD
             }
         }
+        PHASE_STAMP(2);
+#ifdef GEMM_PHASE_STAMP
+        ++phase_round;
+#endif
         if (next >= ntiles) break;
         tile = next;
     }
