@@ -588,7 +588,8 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         // second MFMA group's lgkmcnt need not cover them +2 % on top of that, still below this form; m0 as wave base +
         // literal with the K advance in the DMA's immediate offset -4 % — and note the instruction adds that immediate
         // to the LDS address as well as to the global one.  With all-zero operands the same binary runs 20 % faster
-        // (1.26 -> 1.52 PFLOP/s at 4096^3): under random data the chip holds ~1.94 GHz, not 2.4, in this kernel.)
+        // (1.26 -> 1.52 PFLOP/s at 4096^3): under random data the chip holds ~1.94 GHz, not 2.4, in this kernel.  Issuing
+        // the DMA pieces one at a time inside the MFMA groups instead of in a burst: equal within noise on every shape.)
         for (int kt0 = 0; kt0 < nkt; kt0 += UNR) {
 #pragma unroll
             for (int s = 0; s < UNR; ++s) {
