@@ -180,6 +180,62 @@ __device__ __forceinline__ float max_over_rows(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// fmaxf on MFMA outputs makes the compiler canonicalise each operand first (a v_max_f32 x, x, x per element: 16 extra VALU
+// instructions per score tile in a VALU-bound loop) unless it may assume the operands are not signalling NaNs: this file
+// is built with -fno-honor-nans (Makefile).  (Inline-asm v_max3 on MFMA results is NOT an option: the compiler's hazard
+// recogniser does not cover inline asm, and the MFMA -> VALU read wait states went missing: wrong maxima.)  Hardware
+// behaviour on NaN inputs is unchanged (v_max returns the other operand, arithmetic propagates).
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float vmax2(float a, float b) { return fmaxf(a, b); }
+// max of the 16 scores of one own tile column held by this lane (8 instructions)
+__device__ __forceinline__ float vmax16(const f32x4 (&S)[4]) {
+    float mx = vmax3(S[0][0], S[0][1], S[0][2]);
+    mx = vmax3(mx, S[0][3], S[1][0]);
+    mx = vmax3(mx, S[1][1], S[1][2]);
+    mx = vmax3(mx, S[1][3], S[2][0]);
+    mx = vmax3(mx, S[2][1], S[2][2]);
+    mx = vmax3(mx, S[2][3], S[3][0]);
+    mx = vmax3(mx, S[3][1], S[3][2]);
+    return vmax2(mx, S[3][3]);
+}
+__device__ __forceinline__ float max_over_rows_raw(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// mma_tr_pair for the forward's P V product with the row sums of P taken on the matrix pipe as well: one more MFMA per
+// own tile and half with an all-ones A operand leaves sum_k P[k][query] in every register of lsum (all four lane groups
+// alike, so no cross-lane step at the end) — 21 VALU adds per tile traded for 4 MFMAs on a pipe that is 30 % busy.  The
+// sum is taken over the bf16-rounded probabilities, the ones P V multiplies with.
+template <int D>
+__device__ __forceinline__ void mma_tr_pair_sum(f32x4 (&acc0)[D / 16], f32x4 (&acc1)[D / 16], f32x4& lsum0, f32x4& lsum1,
+                                                const bf16_t* X, int h, const f32x4& W0a, const f32x4& W0b,
+                                                const f32x4& W1a, const f32x4& W1b, int lane) {
+    constexpr int LS = D + Op<bf16_t>::PAD;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    bf16x8 b0, b1, ones;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        b0[j] = (__bf16)W0a[j]; b0[4 + j] = (__bf16)W0b[j];
+        b1[j] = (__bf16)W1a[j]; b1[4 + j] = (__bf16)W1b[j];
+        ones[j] = (__bf16)1.0f; ones[4 + j] = (__bf16)1.0f;
+    }
+    const bf16_t* r0 = X + (32 * h + 4 * g + q) * LS + 4 * p;
+    const bf16_t* r1 = r0 + 16 * LS;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) {
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } a;
+        a.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + dt * 16));
+        a.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r1 + dt * 16));
+        acc0[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0, acc0[dt], 0, 0, 0);
+        acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b1, acc1[dt], 0, 0, 0);
+    }
+    lsum0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0, lsum0, 0, 0, 0);
+    lsum1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1, lsum1, 0, 0, 0);
+}
+
 // Staging of rows [r0, r0+64) of a strided [rows, D] global matrix into LDS (zero beyond nrows), 16-byte chunks, split
 // in two halves: stage_load puts the tile into registers, stage_store parks it in LDS.  The kernels issue the loads
 // of tile t+1 right after tile t has been parked, so the global-memory latency runs under tile t's MFMA / softmax work.
@@ -190,6 +246,8 @@ template <typename T, int D> struct TileRegs {
     static_assert(TILE * CPR % 256 == 0, "tile chunks divide over the block");
     uint4 v[NCH];
 };
+// (An unguarded variant for the mask-free instantiations was tried: hipcc then keeps the tile registers in scratch memory
+// — scratch_store right behind each global load — and the forward goes from 78 to 150 us.)
 template <typename T, int D>
 __device__ __forceinline__ void stage_load(TileRegs<T, D>& t, const T* g, int64_t ls, int r0, int nrows) {
     using R = TileRegs<T, D>;
@@ -320,6 +378,7 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         qf[mt] = qrow[mt] < sh.Lq ? load_rowfrag<T, D>(qb + (int64_t)qrow[mt] * sh.q_ls, g) : zero_rowfrag<T, D>();
     }
     float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};  // bf16: row sums on the matrix pipe
     f32x4 acc[2][D / 16];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -358,6 +417,48 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
         }
         // running max on the raw scores (the scale is positive); the scale is folded into the exponent's fma
         float ms[2];
+        if constexpr (sizeof(T) == 2) {
+            // bf16: the loop is VALU-issue-bound (SQ counters: vector issue 77 % busy, matrix pipe 30 %), so instructions
+            // are what is saved here.  The accumulators are rescaled only when some query's maximum has grown by more
+            // than 2^RESCALE_LOG2 since the last rescale (one wave-uniform branch; until then the exponent is taken against
+            // the older, smaller maximum: probabilities up to 2^8, exact in fp32 and well inside bf16's range; the LSE
+            // written at the end is m + log2(sum) whatever m was used) — on the training shapes that is the first tile only.
+            constexpr float RESCALE_LOG2 = 8.0f;
+            float mn[2];
+            bool grow = false;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float mx = max_over_rows_raw(vmax16(S[mt])) * sl2;
+                mn[mt] = vmax2(m[mt], mx);
+                grow |= mn[mt] > m[mt] + RESCALE_LOG2;
+            }
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float mref = mn[mt] == -INFINITY ? 0.f : mn[mt];
+                    const float alpha = fast_exp2(m[mt] - mref);
+                    m[mt] = mn[mt];
+                    lacc[mt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < D / 16; ++dt) acc[mt][dt] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) ms[mt] = m[mt] == -INFINITY ? 0.f : m[mt];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            S[mt][2 * hh + tt][r] = fast_exp2(fmaf(S[mt][2 * hh + tt][r], sl2, -ms[mt]));
+                mma_tr_pair_sum<D>(acc[0], acc[1], lacc[0], lacc[1], (const bf16_t*)Vs, hh, S[0][2 * hh], S[0][2 * hh + 1],
+                                   S[1][2 * hh], S[1][2 * hh + 1], lane);
+            }
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             float mx = -INFINITY;
@@ -393,8 +494,12 @@ attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __res
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         float l = lsum[mt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        if constexpr (sizeof(T) == 2) {
+            l = lacc[mt][0];
+        } else {
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         if (qrow[mt] < sh.Lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
             T* orow = o + av.oo + (int64_t)qrow[mt] * sh.o_ls + (int64_t)h * D;

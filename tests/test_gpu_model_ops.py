@@ -432,7 +432,9 @@ def test_attention(d, dtype, Lq, Lk, masked):
     s = torch.einsum("blhd,bmhd->bhlm", q, k) * d ** -0.5
     if mask is not None:
         s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
-    assert_close(lse, torch.logsumexp(s, -1), 1e-4, 1e-4, "lse")
+    # bf16: the row sum is taken (on the matrix pipe) over the bf16-rounded probabilities that P V multiplies with
+    lse_tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert_close(lse, torch.logsumexp(s, -1), lse_tol, lse_tol, "lse")
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
     ops.attn_bwd(qd, kd, vd, o, dout.to(DEV).to(dtype), lse, dq, dk, dv, md)
     tolb = 5e-5 if dtype == torch.float32 else 2e-2

@@ -11,10 +11,11 @@ lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "ab_libs", "libse
 h = ctypes.CDLL(lib)
 h.sedd_gemm_nt.restype = ctypes.c_int
 P, L, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
-for M, N, K, epi in ((32768, 3072, 768, 2), (32768, 3072, 768, 0), (32768, 768, 3072, 0), (4096, 4096, 4096, 0)):
+for M, N, K, epi, want_pre in ((32768, 3072, 768, 2, 1), (32768, 3072, 768, 2, 0), (32768, 3072, 768, 1, 0), (32768, 3072, 768, 0, 0),
+                             (32768, 768, 3072, 0, 0), (4096, 4096, 4096, 0, 0)):
     A = torch.randn(M, K, device="cuda").bfloat16(); B = torch.randn(N, K, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if epi == 2 else None
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if want_pre else None
     bias = torch.randn(N, device="cuda") if epi else None
     def run():
         assert h.sedd_gemm_nt(P(A.data_ptr()), L(K), P(B.data_ptr()), L(K), P(C.data_ptr()), L(N), I(1), I(1),
@@ -32,7 +33,7 @@ for M, N, K, epi in ((32768, 3072, 768, 2), (32768, 3072, 768, 0), (32768, 768, 
     assert h.sedd_debug_gemm_phase(buf) == 0
     rounds = min(8, (M // 256) * (N // (128 if NB == 512 else 256)) // NB)
     t00 = min(buf[(b * 8) * 3] for b in range(NB))
-    print(f"M={M} N={N} K={K} epi={epi}: {us:.1f} us, {2.0*M*N*K/us/1e6:.0f} TF/s, {rounds} rounds", flush=True)
+    print(f"M={M} N={N} K={K} epi={epi} pre={want_pre}: {us:.1f} us, {2.0*M*N*K/us/1e6:.0f} TF/s, {rounds} rounds", flush=True)
     for r, lo in ((r, lo) for r in range(rounds) for lo in range(0, NB, 256)):
         st = sorted((buf[(b * 8 + r) * 3] - t00) / 100.0 for b in range(lo, lo + 256))
         ml = sorted((buf[(b * 8 + r) * 3 + 1] - buf[(b * 8 + r) * 3]) / 100.0 for b in range(lo, lo + 256))
