@@ -179,6 +179,12 @@ def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
     for name, nbytes, fn in (
             ("predictor_step_analytic", M * (V * 2 + V * 4 + 16), lambda: ops.predictor_step(graph, L_.STEP_ANALYTIC, logits, x, sig, u)),
             ("predictor_step_euler", M * (V * 2 + V * 4 + 16), lambda: ops.predictor_step(graph, L_.STEP_EULER, logits, x, sig, u)),
+            # the two ways a sampler step gets its noise (SURVEY 8d "report both"): torch.rand + the kernel that reads it
+            # (bytes: the rand kernel's write included), and the kernel generating Philox4x32-10 noise itself
+            ("rand_plus_predictor_step_analytic", M * (V * 2 + 2 * V * 4 + 16),
+             lambda: ops.predictor_step(graph, L_.STEP_ANALYTIC, logits, x, sig, torch.rand(B, L, V, device=dev))),
+            ("predictor_step_analytic_philox", M * (V * 2 + 16),
+             lambda: ops.predictor_step_philox(graph, L_.STEP_ANALYTIC, logits, x, sig, ops.PhiloxNoise(1234, 7))),
             ("score_entropy_fwd_bwd", M * (2 * V * 2 + 20), lambda: ops.score_entropy_fwd(graph, logits, sig, x, x0, gw=sig))):
         for _ in range(3):
             fn()

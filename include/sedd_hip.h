@@ -71,6 +71,17 @@ int sedd_gumbel_argmax(const void* p, int dtype, const float* u, int64_t* out, i
 int sedd_predictor_step(int graph, int step, const void* logscore, int dtype, const int64_t* x, const float* coef,
                         const float* u, int64_t* xnew, int64_t M, int64_t L, int V, sedd_stream_t stream);
 
+/* The same update with the uniform noise generated in the kernel instead of read from memory — the reference draws it
+ * with torch.rand_like inside sample_categorical (utils/catsample.py:12, called from sampling/sampling.py:79, :98,
+ * :131), one more [M, Vu] fp32 tensor written and read per step.  Noise definition (independent of launch geometry):
+ * u[row][j] = (w >> 8) * 2^-24 with w = word (j & 3) of Philox4x32-10(counter = {row_lo, row_hi, j >> 2, offset},
+ * key = {seed_lo, seed_hi}); offset < 2^32 (the sampler passes its step index).  Results equal
+ * sedd_predictor_step on that u bit for bit.  Row-per-lane path only (V <= 64, V * elem_size not a multiple of 32,
+ * 16-byte aligned log-score), else SEDD_ERR_UNSUPPORTED_SHAPE.  HBM bytes M (V e + 16) instead of M (V e + 4 Vu + 16). */
+int sedd_predictor_step_philox(int graph, int step, const void* logscore, int dtype, const int64_t* x, const float* coef,
+                               uint64_t seed, uint64_t offset, int64_t* xnew, int64_t M, int64_t L, int V,
+                               sedd_stream_t stream);
+
 /* Stand-alone Graph methods (for Graph-API parity; the predictor kernel above fuses them).  All outputs fp32
  * [M, V].  graph_lib.py:218-221/:139-145 (transp_rate), :79-93 (reverse_rate), :264-269/:162-165
  * (staggered_score), :226-234/:147-154 (transp_transition). score fp32 [M,V]; sig fp32 [B]. */

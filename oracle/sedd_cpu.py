@@ -208,6 +208,39 @@ def denoise_step(graph, logits, x, sigma, u):
 
 
 # --------------------------------------------------------------------------------------------- model pieces
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11, section 3.3 and
+    the Random123 reference constants) on numpy uint32 arrays: counter [..., 4], key [..., 2] -> [..., 4].  No
+    counterpart in the reference (it draws torch.rand_like, utils/catsample.py:12); this restates the published
+    generator that sedd_predictor_step_philox runs in-kernel."""
+    import numpy as np
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k0 = np.asarray(key[..., 0], dtype=np.uint64)
+    k1 = np.asarray(key[..., 1], dtype=np.uint64)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), \
+        np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack(c, -1).astype(np.uint32)
+
+
+def philox_uniform(seed, offset, M, Vu):
+    """The [M, Vu] uniforms of sedd_predictor_step_philox (include/sedd_hip.h): word (j & 3) of
+    philox(counter = {row_lo, row_hi, j >> 2, offset}, key = {seed_lo, seed_hi}); u = (word >> 8) * 2^-24."""
+    import numpy as np
+    nq = (Vu + 3) // 4
+    rows = np.arange(M, dtype=np.uint64)[:, None].repeat(nq, 1)
+    ctr = np.stack([rows & np.uint64(0xFFFFFFFF), rows >> np.uint64(32),
+                    np.arange(nq, dtype=np.uint64)[None, :].repeat(M, 0), np.full((M, nq), offset, dtype=np.uint64)], -1)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = np.broadcast_to(np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint64), (M, nq, 2))
+    w = philox4x32_10(ctr, key).reshape(M, nq * 4)[:, :Vu]
+    return torch.from_numpy(((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)))
+
+
 def timestep_embedding(sigma, dim=256, max_period=10000):
     """transformer.py:70-89"""
     half = dim // 2

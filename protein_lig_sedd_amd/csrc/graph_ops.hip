@@ -603,11 +603,34 @@ __global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step
 // things found on the way apply here: `__syncthreads()` = vmcnt(0) + barrier drains every in-flight LDS-DMA, and LDS
 // reads placed under the `j < V` guards compile to one round trip per element (the row is now read unguarded, in one
 // batch: 29.7 -> 28.2 us).
-template <typename T, int VP, int graph, int step>
+// Philox4x32-10 (Salmon et al., SC'11; the counter-based generator behind curand / torch's device RNG): four 32-bit words
+// from a 128-bit counter and a 64-bit key.  sedd_predictor_step_philox draws the uniform of (row, vocabulary slot j) as
+// word (j & 3) of philox(counter = {row_lo, row_hi, j >> 2, offset}, key = {seed_lo, seed_hi}), u = (word >> 8) * 2^-24
+// in [0, 1) — a function of (seed, offset, row, j) only, so results do not depend on the launch geometry.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// PHILOX: the uniforms are generated in registers (above) instead of being staged from `u`: M (V e + 16) bytes instead
+// of M (V e + 4 Vu + 16), at ~10 quarter-rate integer multiplies per uniform.
+template <typename T, int VP, int graph, int step, bool PHILOX = false>
 __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
     predictor_step_rows_kernel(const T* __restrict__ ls, const int64_t* __restrict__ x,
                                const float* __restrict__ coef, const float* __restrict__ u,
-                               int64_t* __restrict__ xnew, int64_t M, int64_t L, int V) {
+                               int64_t* __restrict__ xnew, int64_t M, int64_t L, int V, uint64_t seed = 0,
+                               uint32_t offset = 0) {
     constexpr int ROWS = RowsCfg<VP>::ROWS;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_cnt;
@@ -622,7 +645,7 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
     const int tid = threadIdx.x;
     if (tid == 0) s_cnt = 0;
     rows_stage_in((const unsigned char*)(ls + row0 * V), smem, nrows * V * (int)sizeof(T), ROWS);
-    rows_stage_in((const unsigned char*)(u + row0 * Vu), s_u, nrows * Vu * 4, ROWS);
+    if constexpr (!PHILOX) rows_stage_in((const unsigned char*)(u + row0 * Vu), s_u, nrows * Vu * 4, ROWS);
     const int64_t xi64 = tid < nrows ? x[row0 + tid] : 0;
     const float cf_own = tid < nrows ? coef[(row0 + tid) / L] : 0.f;  // fetched under the staging latency
     rows_stage_wait();
@@ -662,8 +685,24 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
         T raw[VP];
 #pragma unroll
         for (int j = 0; j < VP; ++j) raw[j] = lrow[j];
+        if constexpr (PHILOX) {
 #pragma unroll
-        for (int j = 0; j < VP; ++j) un[j] = urow[j];
+            for (int q4 = 0; q4 < VP / 4; ++q4) {
+                if (4 * q4 < Vu) {  // (wave-uniform)
+                    uint32_t w[4];
+                    philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)q4, offset, (uint32_t)seed,
+                                  (uint32_t)(seed >> 32), w);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) un[4 * q4 + c] = (float)(w[c] >> 8) * 5.9604644775390625e-8f;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) un[4 * q4 + c] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VP; ++j) un[j] = urow[j];
+        }
 #pragma unroll
         for (int j = 0; j < VP; ++j) e[j] = to_f32<T>(raw[j]);
     }
@@ -722,6 +761,49 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
         }
     }
     xnew[row] = am.result();
+}
+
+extern "C" int sedd_predictor_step_philox(int graph, int step, const void* logscore, int dtype, const int64_t* x,
+                                          const float* coef, uint64_t seed, uint64_t offset, int64_t* xnew, int64_t M,
+                                          int64_t L, int V, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(graph == SEDD_ABSORB || graph == SEDD_UNIFORM, "predictor_step_philox: unknown graph %d", graph);
+    SEDD_CHECK_ARG(step >= SEDD_STEP_EULER && step <= SEDD_STEP_DENOISE, "predictor_step_philox: unknown step %d", step);
+    SEDD_CHECK_ARG(dtype == SEDD_F32 || dtype == SEDD_BF16, "predictor_step_philox: unknown dtype %d", dtype);
+    SEDD_CHECK_ARG(M == 0 || (logscore && x && coef && xnew), "predictor_step_philox: null pointer");
+    SEDD_CHECK_ARG(M >= 0 && L > 0 && V > 1 && M % L == 0, "predictor_step_philox: bad sizes M=%ld L=%ld V=%d", (long)M,
+                   (long)L, V);
+    SEDD_CHECK_ARG(offset < (1ull << 32), "predictor_step_philox: offset must fit 32 bits");
+    if (M == 0) return SEDD_OK;
+    const int esz = dtype == SEDD_F32 ? 4 : 2;
+    if (!rows_path_ok(V, esz, 0, logscore, nullptr, nullptr)) {
+        sedd_set_error("predictor_step_philox: only the row-per-lane path (V <= 64, V * elem_size not a multiple of 32, "
+                       "16-byte aligned log-score) generates its noise in-kernel; V=%d", V);
+        return SEDD_ERR_UNSUPPORTED_SHAPE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define PRED_PHILOX(T, GR, ST)                                                                                        \
+    SEDD_DISPATCH_VP(V, hipLaunchKernelGGL((predictor_step_rows_kernel<T, VP, GR, ST, true>),                         \
+                                           dim3((unsigned)((M + RowsCfg<VP>::ROWS - 1) / RowsCfg<VP>::ROWS)),         \
+                                           dim3(RowsCfg<VP>::ROWS), rows_lds(RowsCfg<VP>::ROWS, V * (int)sizeof(T)) + 256, \
+                                           st, (const T*)logscore, x, coef, (const float*)nullptr, xnew, M, L, V, seed,   \
+                                           (uint32_t)offset))
+#define PRED_PHILOX_ST(T, GR)                                                        \
+    do {                                                                             \
+        if (step == SEDD_STEP_EULER) PRED_PHILOX(T, GR, SEDD_STEP_EULER);            \
+        else if (step == SEDD_STEP_ANALYTIC) PRED_PHILOX(T, GR, SEDD_STEP_ANALYTIC); \
+        else PRED_PHILOX(T, GR, SEDD_STEP_DENOISE);                                  \
+    } while (0)
+    if (dtype == SEDD_F32) {
+        if (graph == SEDD_ABSORB) PRED_PHILOX_ST(float, SEDD_ABSORB);
+        else PRED_PHILOX_ST(float, SEDD_UNIFORM);
+    } else {
+        if (graph == SEDD_ABSORB) PRED_PHILOX_ST(bf16_t, SEDD_ABSORB);
+        else PRED_PHILOX_ST(bf16_t, SEDD_UNIFORM);
+    }
+#undef PRED_PHILOX_ST
+#undef PRED_PHILOX
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
 }
 
 extern "C" int sedd_predictor_step(int graph, int step, const void* logscore, int dtype, const int64_t* x,

@@ -91,6 +91,8 @@ class Graph(abc.ABC):
         """Fused Euler / Analytic / Denoiser update (sampling.py:61-132) on the model's log-score."""
         V = logscore.shape[-1]
         Vu = V - 1 if (self.absorb and step == _L.STEP_DENOISE) else V
+        if isinstance(u, ops.PhiloxNoise):  # opt-in: noise generated inside the kernel
+            return ops.predictor_step_philox(self, step, logscore, x, coef, u)
         if u is None:
             u = torch.rand(*x.shape, Vu, dtype=torch.float32, device=x.device)
         return ops.predictor_step(self, step, logscore, x, coef, u)

@@ -176,6 +176,42 @@ def predictor_step(graph, step, logscore, x, coef, u):
     return out
 
 
+class PhiloxNoise:
+    """Stands in for a predictor update's uniform tensor `u`: the kernel generates it (Philox4x32-10 keyed by `seed`,
+    counter (row, vocabulary slot / 4, offset) — include/sedd_hip.h, sedd_predictor_step_philox) instead of reading a
+    torch.rand tensor.  The reference draws that tensor with torch.rand_like in utils/catsample.py:12."""
+    __slots__ = ("seed", "offset")
+
+    def __init__(self, seed, offset=0):
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset)
+        if not 0 <= self.offset < 2 ** 32:
+            raise ValueError("PhiloxNoise offset must fit 32 bits")
+
+
+class PhiloxStream:
+    """`noise_seq` for get_pc_sampler: update i draws its noise in-kernel with PhiloxNoise(seed, i)."""
+
+    def __init__(self, seed):
+        self.seed = int(seed)
+
+    def __getitem__(self, i):
+        return PhiloxNoise(self.seed, i)
+
+
+def predictor_step_philox(graph, step, logscore, x, coef, noise):
+    _cuda(logscore, x, coef)
+    logscore, x = _c(logscore), _c(x, torch.int64)
+    B, M, L = _rows(x)
+    V = logscore.shape[-1]
+    out = torch.empty_like(x)
+    seed = noise.seed - (1 << 64) if noise.seed >= (1 << 63) else noise.seed  # (the binding passes int64)
+    with _Timed("predictor_step_philox", float(M) * (V * logscore.element_size() + 16)):
+        check(lib().sedd_predictor_step_philox(graph.code, step, _p(logscore), _dt(logscore), _p(x),
+                                               _p(_batch_scalar(coef, B)), seed, noise.offset, _p(out), M, L, V,
+                                               _stream()), "sedd_predictor_step_philox")
+    return out
+
+
 def transp_rate(graph, x):
     x = _c(x, torch.int64)
     out = torch.empty(*x.shape, graph.dim, dtype=torch.float32, device=x.device)

@@ -140,7 +140,8 @@ def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps
 
     @torch.no_grad()
     def pc_sampler(model, task=None, prot_indices=None, lig_indices=None, noise_seq=None, x_init=None):
-        """noise_seq: optional sequence of `steps` (+1 when denoising) uniform tensors, one per update."""
+        """noise_seq: optional sequence of `steps` (+1 when denoising) uniform tensors, one per update — or
+        ops.PhiloxStream(seed), with which every update generates its noise inside the predictor kernel."""
         x = graph.sample_limit(*batch_dims).to(device) if x_init is None else x_init.to(device)
         timesteps = torch.linspace(1, eps, steps + 1, device=device)
         dt = (1 - eps) / steps

@@ -62,6 +62,8 @@ def test_argument_validation_without_gpu():
     # empty problems are fine without pointers
     assert L.sedd_score_entropy_fwd(0, None, 0, None, None, None, None, None, None, 0, 4, 26, None) == 0
     assert L.sedd_predictor_step(0, 0, None, 1, None, None, None, None, 0, 8, 26, None) == 0
+    assert L.sedd_predictor_step_philox(0, 1, None, 1, None, None, 1, 2 ** 32, None, 0, 8, 26, None) == -1
+    assert b"32 bits" in L.sedd_last_error()
     # unsupported shapes report SEDD_ERR_UNSUPPORTED_SHAPE (-2)
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)

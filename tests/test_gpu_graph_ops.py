@@ -181,6 +181,65 @@ def test_predictor_steps_vs_oracle(V, dtype):
             assert int((out == V - 1).sum()) == 0  # the denoiser never leaves a mask
 
 
+@pytest.mark.parametrize("V", [9, 26, 37, 63])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_predictor_step_philox_matches_explicit_noise_and_oracle(V, dtype):
+    """sedd_predictor_step_philox = sedd_predictor_step on the uniforms the header defines (oracle.philox_uniform: the
+    published Philox4x32-10, pinned by the Random123 known answers in the CPU suite) = the oracle's step; bit-exact."""
+    from protein_lig_sedd_amd import _lib as L, ops
+    GL = _graphs()
+    torch.manual_seed(100 + V)
+    B, Ln = 3, 171  # ragged last tile of rows
+    noise = O.make_noise("loglinear", eps=1e-3)
+    seed, offset = 0x9E3779B97F4A7C15, 41  # a seed above 2^63: passes through the signed binding intact
+    for graph, og in ((GL.Absorbing(V - 1), O.AbsorbingCPU(V - 1)), (GL.Uniform(V), O.UniformCPU(V))):
+        x = torch.randint(0, V, (B, Ln))
+        if og.absorb:
+            x[torch.rand(B, Ln) < 0.6] = V - 1
+        logits = (torch.randn(B, Ln, V) * 2 - 3).to(dtype)
+        t = torch.rand(B, 1) * 0.9 + 0.05
+        sig, dsig = noise(t)
+        dt = 0.01
+        ds = sig - noise(t - dt)[0]
+        u = O.philox_uniform(seed, offset, B * Ln, V).view(B, Ln, V)
+        ud = O.philox_uniform(seed, offset, B * Ln, V - 1).view(B, Ln, V - 1) if og.absorb else u
+        cases = ((L.STEP_EULER, dt * dsig, u, O.euler_step(og, logits, x, (sig, dsig), dt, u)),
+                 (L.STEP_ANALYTIC, ds, u, O.analytic_step(og, logits, x, ds, u)),
+                 (L.STEP_DENOISE, sig, ud, O.denoise_step(og, logits, x, sig, ud)))
+        for step, coef, uu, ref in cases:
+            out = graph.predictor_step(step, logits.to(DEV), x.to(DEV), coef.to(DEV), u=ops.PhiloxNoise(seed, offset))
+            exp = graph.predictor_step(step, logits.to(DEV), x.to(DEV), coef.to(DEV), u=uu.to(DEV))
+            assert _mismatch(out, exp) == 0, f"step {step}: in-kernel noise vs the same noise passed in"
+            assert _mismatch(out, ref) == 0, f"step {step}: vs oracle"
+        other = graph.predictor_step(L.STEP_ANALYTIC, logits.to(DEV), x.to(DEV), ds.to(DEV), u=ops.PhiloxNoise(seed, offset + 1))
+        assert _mismatch(other, cases[1][3]) > 0  # another offset is another draw
+
+
+def test_pc_sampler_with_philox_stream_equals_explicit_noise_sequence():
+    """get_pc_sampler(noise_seq=PhiloxStream(seed)) = the same sampler fed the tensors philox_uniform defines."""
+    from protein_lig_sedd_amd import ops, sampling, noise_lib
+    GL = _graphs()
+    V, B, Ln, steps = 26, 4, 96, 5
+    graph = GL.Absorbing(V - 1)
+    noise = noise_lib.LogLinearNoise()
+    torch.manual_seed(5)
+    W = torch.randn(V, V, device=DEV) * 0.5
+
+    class Model(torch.nn.Module):  # a stand-in score model: log-score depends on the token and the noise level
+        def forward(self, x, sigma):
+            return (W[x] - sigma.view(-1, 1, 1)).bfloat16()
+
+    model = Model()
+
+    for name in ("euler", "analytic"):
+        fn = sampling.get_pc_sampler(graph, noise, (B, Ln), name, steps, denoise=True, device=torch.device(DEV))
+        a = fn(model, noise_seq=ops.PhiloxStream(77))
+        seq = [O.philox_uniform(77, i, B * Ln, V if i < steps else V - 1).view(B, Ln, -1).to(DEV) for i in range(steps + 1)]
+        b = fn(model, noise_seq=seq)
+        assert _mismatch(a, b) == 0, name
+        assert int((a == V - 1).sum()) == 0
+
+
 def _misaligned(t):
     """same values at an address that is not 16-byte aligned (routes the C ABI to the lane-group kernels)."""
     buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
@@ -250,6 +309,12 @@ def test_abi_rejects_bad_arguments():
         ops.predictor_step(GL.Absorbing(25), 7, torch.zeros(1, 4, 26, device=DEV),
                            torch.zeros(1, 4, dtype=torch.int64, device=DEV), torch.zeros(1, device=DEV),
                            torch.rand(1, 4, 26, device=DEV))
+    with pytest.raises(SeddError, match="row-per-lane"):  # in-kernel noise exists on the V <= 64 path only
+        ops.predictor_step_philox(GL.Uniform(300), 1, torch.zeros(1, 4, 300, device=DEV),
+                                  torch.zeros(1, 4, dtype=torch.int64, device=DEV), torch.zeros(1, device=DEV),
+                                  ops.PhiloxNoise(1, 0))
+    with pytest.raises(ValueError):
+        ops.PhiloxNoise(1, 2 ** 32)
     with pytest.raises(RuntimeError):
         ops.gumbel_argmax(torch.rand(4, 26), torch.rand(4, 26))  # CPU tensors: no fallback
     with pytest.raises(ValueError):

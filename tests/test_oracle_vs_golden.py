@@ -423,3 +423,21 @@ def test_g19_varlen_block(golden):
         with torch.no_grad():  # the hook matters: one-segment-per-row attention gives a different result
             assert float((O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g[t + "x"], g[t + "c"], H) - g[t + "y"]).abs().max()) > 1e-3
             assert_close(O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g[t + "x"], g[t + "c"], H), g[t + "y_rows"], 1e-5, 1e-5)
+
+
+def test_philox4x32_10_known_answers():
+    """The oracle's Philox4x32-10 against the Random123 known-answer vectors (kat_vectors: zero, all-ones and pi-digit
+    counters / keys) — the generator sedd_predictor_step_philox runs in-kernel; and the uniform map's range."""
+    import numpy as np
+    kat = (([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]))
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+        assert [int(v) for v in got] == want
+    u = O.philox_uniform(1234, 7, 4096, 26)
+    assert u.shape == (4096, 26) and float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.01
+    assert not torch.equal(u, O.philox_uniform(1234, 8, 4096, 26))
+    assert torch.equal(u[:, :25], O.philox_uniform(1234, 7, 4096, 25))  # slot j does not depend on the row width
