@@ -300,6 +300,12 @@ __device__ __forceinline__ void stage_put4(unsigned char* reg, int row_l, int co
     store_row4<TO>(reinterpret_cast<TO*>(reg + row_l * StageCfg<TO>::PITCH) + col_l, v);
 }
 // flush one pass: rows [row_g, row_g + RPP) x columns [col_g, col_g + 64) of C; accumulate adds the old C (fp32/bf16)
+// (Round 2 tried to take the per-chunk 64-bit row * ldc multiplies and bound compares out of the pass loops — a per-tile
+// lane context with wave-uniform pass offsets, then with running pointers: the first form had the compiler hoist a
+// (pass, group) table of 64-bit offsets into SGPRs and spill 136-152 of them to VGPR lanes, the second spilled 14-82
+// VGPRs in the 256-wide kernels, which sit at the 256-register limit; both measured slower — fc1 epilogue 10.4 -> 12.6 us
+// per tile, dGELU 19.4 -> 24 us.  tools/gemm_phase.py has the per-tile phase times: plain bf16 epilogue 4.0 us = the
+// CU's store rate (128 KB at ~16 B/clk), GELU + pre 10.4 us, dGELU 19.4 us, rotary 5.3 us per 256 x 128 tile.)
 template <typename TO>
 __device__ __forceinline__ void stage_flush(const unsigned char* reg, TO* __restrict__ C, int64_t ldc, int64_t row_g,
                                             int64_t col_g, int64_t M, int64_t N, int lane, int accumulate) {

@@ -40,3 +40,48 @@ for M, N, K, epi, want_pre in ((32768, 3072, 768, 2, 1), (32768, 3072, 768, 2, 0
         ep = sorted((buf[(b * 8 + r) * 3 + 2] - buf[(b * 8 + r) * 3 + 1]) / 100.0 for b in range(lo, lo + 256))
         print(f"  round {r} blocks {lo}+: start {st[0]:.1f}..{st[128]:.1f}..{st[-1]:.1f} us   main loop {ml[0]:.1f}/{ml[128]:.1f}/{ml[-1]:.1f} us"
               f"   epilogue {ep[0]:.1f}/{ep[128]:.1f}/{ep[-1]:.1f} us (min/median/max)", flush=True)
+
+# the fused dGELU data gradient (dX = (dY W2) * gelu'(u): M x 3072, K = 768, B as [K, N]) and the QKV projection with rotary
+def phase_report(tag, us, flops, NB_, tiles):
+    buf = (ctypes.c_uint64 * (512 * 8 * 3))()
+    assert h.sedd_debug_gemm_phase(buf) == 0
+    rounds = min(8, max(1, tiles // NB_))
+    print(f"{tag}: {us:.1f} us, {flops/us/1e6:.0f} TF/s, {rounds} rounds", flush=True)
+    for r in range(rounds):
+        ml = sorted((buf[(b * 8 + r) * 3 + 1] - buf[(b * 8 + r) * 3]) / 100.0 for b in range(256))
+        ep = sorted((buf[(b * 8 + r) * 3 + 2] - buf[(b * 8 + r) * 3 + 1]) / 100.0 for b in range(256))
+        print(f"  round {r}: main loop {ml[0]:.1f}/{ml[128]:.1f}/{ml[-1]:.1f} us   epilogue {ep[0]:.1f}/{ep[128]:.1f}/{ep[-1]:.1f} us", flush=True)
+
+def bench(fn):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 200 * 1e3
+
+if NB == 256:
+    M, N, K = 32768, 3072, 768
+    dY = torch.randn(M, K, device="cuda").bfloat16(); W2 = torch.randn(K, N, device="cuda").bfloat16()
+    pre = torch.randn(M, N, device="cuda").bfloat16(); C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    cs = torch.zeros(N, device="cuda")
+    h.sedd_gemm_nn_dgelu.restype = ctypes.c_int
+    def run_dg():
+        assert h.sedd_gemm_nn_dgelu(P(dY.data_ptr()), L(K), P(W2.data_ptr()), L(N), P(C.data_ptr()), L(N), I(1), I(1),
+                                    P(pre.data_ptr()), P(cs.data_ptr()), L(M), L(N), L(K), P(torch.cuda.current_stream().cuda_stream)) == 0
+    phase_report("dGELU NN M=32768 N=3072 K=768", bench(run_dg), 2.0 * M * N * K, 256, (M // 256) * (N // 256))
+    N = 2304
+    X = torch.randn(M, K, device="cuda").bfloat16(); Wq = torch.randn(N, K, device="cuda").bfloat16()
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    cos = torch.rand(512, 32, device="cuda"); sin = torch.rand(512, 32, device="cuda")
+    h.sedd_gemm_nt_rotary.restype = ctypes.c_int
+    def run_rot():
+        assert h.sedd_gemm_nt_rotary(P(X.data_ptr()), L(K), P(Wq.data_ptr()), L(K), P(C.data_ptr()), L(N), I(1), I(1), P(0), I(0),
+                                     P(cos.data_ptr()), P(sin.data_ptr()), I(512), I(12), I(64), L(M), L(N), L(K),
+                                     P(torch.cuda.current_stream().cuda_stream)) == 0
+    phase_report("QKV rotary M=32768 N=2304 K=768 (256 x 128 tiles)", bench(run_rot), 2.0 * M * N * K, 256, (M // 256) * (N // 128))
+    def run_plain():
+        assert h.sedd_gemm_nt(P(X.data_ptr()), L(K), P(Wq.data_ptr()), L(K), P(C.data_ptr()), L(N), I(1), I(1), P(0), I(0), P(0),
+                              I(0), L(M), L(N), L(K), P(torch.cuda.current_stream().cuda_stream)) == 0
+    phase_report("QKV plain  M=32768 N=2304 K=768", bench(run_plain), 2.0 * M * N * K, 256, (M // 256) * (N // 256))
