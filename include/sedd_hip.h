@@ -82,6 +82,11 @@ int sedd_predictor_step_philox(int graph, int step, const void* logscore, int dt
                                uint64_t seed, uint64_t offset, int64_t* xnew, int64_t M, int64_t L, int V,
                                sedd_stream_t stream);
 
+/* The uniforms sedd_predictor_step_philox draws, written out as u fp32 [M, Vu] (same definition): for shapes its
+ * row-per-lane path does not take (V > 64, unaligned log-scores) a host gets the same stream by calling this and then
+ * sedd_predictor_step; no counterpart in the reference (torch.rand_like, utils/catsample.py:12). */
+int sedd_philox_uniform(uint64_t seed, uint64_t offset, float* u, int64_t M, int Vu, sedd_stream_t stream);
+
 /* Stand-alone Graph methods (for Graph-API parity; the predictor kernel above fuses them).  All outputs fp32
  * [M, V].  graph_lib.py:218-221/:139-145 (transp_rate), :79-93 (reverse_rate), :264-269/:162-165
  * (staggered_score), :226-234/:147-154 (transp_transition). score fp32 [M,V]; sig fp32 [B]. */

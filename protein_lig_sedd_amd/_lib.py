@@ -24,6 +24,7 @@ SIGNATURES = {
     "sedd_gumbel_argmax": "pipplip",
     "sedd_predictor_step": "iipippppllip",
     "sedd_predictor_step_philox": "iipippllpllip",
+    "sedd_philox_uniform": "llplip",
     "sedd_transp_rate": "ipplip",
     "sedd_reverse_rate": "ippplip",
     "sedd_staggered_score": "ippplli" + "p",

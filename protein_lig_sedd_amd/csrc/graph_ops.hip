@@ -763,6 +763,36 @@ __global__ void __launch_bounds__(RowsCfg<VP>::ROWS)
     xnew[row] = am.result();
 }
 
+// the uniforms of sedd_predictor_step_philox as a tensor: thread -> (row, group of four slots)
+__global__ void __launch_bounds__(TPB) philox_uniform_kernel(uint64_t seed, uint32_t offset, float* __restrict__ u,
+                                                             int64_t M, int Vu, int nq) {
+    const int64_t total = M * nq;
+    for (int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x; t < total; t += (int64_t)gridDim.x * TPB) {
+        const int64_t row = t / nq;
+        const int q4 = (int)(t % nq);
+        uint32_t w[4];
+        philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)q4, offset, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), w);
+        float* dst = u + row * Vu + 4 * q4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * q4 + c < Vu) dst[c] = (float)(w[c] >> 8) * 5.9604644775390625e-8f;
+    }
+}
+
+extern "C" int sedd_philox_uniform(uint64_t seed, uint64_t offset, float* u, int64_t M, int Vu, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(M >= 0 && Vu > 0, "philox_uniform: bad sizes M=%ld Vu=%d", (long)M, Vu);
+    SEDD_CHECK_ARG(offset < (1ull << 32), "philox_uniform: offset must fit 32 bits");
+    SEDD_CHECK_ARG(M == 0 || u, "philox_uniform: null pointer");
+    if (M == 0) return SEDD_OK;
+    const int nq = (Vu + 3) / 4;
+    const int64_t blocks = (M * nq + TPB - 1) / TPB;
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(TPB), 0,
+                       (hipStream_t)stream, seed, (uint32_t)offset, u, M, Vu, nq);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
 extern "C" int sedd_predictor_step_philox(int graph, int step, const void* logscore, int dtype, const int64_t* x,
                                           const float* coef, uint64_t seed, uint64_t offset, int64_t* xnew, int64_t M,
                                           int64_t L, int V, sedd_stream_t stream) {

@@ -206,9 +206,16 @@ def predictor_step_philox(graph, step, logscore, x, coef, noise):
     out = torch.empty_like(x)
     seed = noise.seed - (1 << 64) if noise.seed >= (1 << 63) else noise.seed  # (the binding passes int64)
     with _Timed("predictor_step_philox", float(M) * (V * logscore.element_size() + 16)):
-        check(lib().sedd_predictor_step_philox(graph.code, step, _p(logscore), _dt(logscore), _p(x),
-                                               _p(_batch_scalar(coef, B)), seed, noise.offset, _p(out), M, L, V,
-                                               _stream()), "sedd_predictor_step_philox")
+        rc = lib().sedd_predictor_step_philox(graph.code, step, _p(logscore), _dt(logscore), _p(x),
+                                              _p(_batch_scalar(coef, B)), seed, noise.offset, _p(out), M, L, V, _stream())
+    if rc == -2:
+        # shapes the row-per-lane kernel does not take (the ligand vocabulary, unaligned views): the same uniforms as a
+        # tensor, then the explicit-noise kernel — identical results, one more pass over [M, Vu]
+        Vu = V - 1 if (graph.code == ABSORB and step == _L.STEP_DENOISE) else V
+        u = torch.empty(*x.shape, Vu, dtype=torch.float32, device=x.device)
+        check(lib().sedd_philox_uniform(seed, noise.offset, _p(u), M, Vu, _stream()), "sedd_philox_uniform")
+        return predictor_step(graph, step, logscore, x, coef, u)
+    check(rc, "sedd_predictor_step_philox")
     return out
 
 

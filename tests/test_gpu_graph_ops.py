@@ -181,7 +181,7 @@ def test_predictor_steps_vs_oracle(V, dtype):
             assert int((out == V - 1).sum()) == 0  # the denoiser never leaves a mask
 
 
-@pytest.mark.parametrize("V", [9, 26, 37, 63])
+@pytest.mark.parametrize("V", [9, 26, 37, 63, 64, 300])  # 64 and 300: the philox_uniform + explicit-noise route
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_predictor_step_philox_matches_explicit_noise_and_oracle(V, dtype):
     """sedd_predictor_step_philox = sedd_predictor_step on the uniforms the header defines (oracle.philox_uniform: the
@@ -309,10 +309,6 @@ def test_abi_rejects_bad_arguments():
         ops.predictor_step(GL.Absorbing(25), 7, torch.zeros(1, 4, 26, device=DEV),
                            torch.zeros(1, 4, dtype=torch.int64, device=DEV), torch.zeros(1, device=DEV),
                            torch.rand(1, 4, 26, device=DEV))
-    with pytest.raises(SeddError, match="row-per-lane"):  # in-kernel noise exists on the V <= 64 path only
-        ops.predictor_step_philox(GL.Uniform(300), 1, torch.zeros(1, 4, 300, device=DEV),
-                                  torch.zeros(1, 4, dtype=torch.int64, device=DEV), torch.zeros(1, device=DEV),
-                                  ops.PhiloxNoise(1, 0))
     with pytest.raises(ValueError):
         ops.PhiloxNoise(1, 2 ** 32)
     with pytest.raises(RuntimeError):
