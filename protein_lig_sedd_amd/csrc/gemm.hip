@@ -305,7 +305,12 @@ __device__ __forceinline__ void stage_put4(unsigned char* reg, int row_l, int co
 // (pass, group) table of 64-bit offsets into SGPRs and spill 136-152 of them to VGPR lanes, the second spilled 14-82
 // VGPRs in the 256-wide kernels, which sit at the 256-register limit; both measured slower — fc1 epilogue 10.4 -> 12.6 us
 // per tile, dGELU 19.4 -> 24 us.  tools/gemm_phase.py has the per-tile phase times: plain bf16 epilogue 4.0 us = the
-// CU's store rate (128 KB at ~16 B/clk), GELU + pre 10.4 us, dGELU 19.4 us, rotary 5.3 us per 256 x 128 tile.)
+// CU's store rate (128 KB at ~16 B/clk), GELU + pre 10.4 us, dGELU 19.4 us, rotary 5.3 us per 256 x 128 tile.
+// Also tried, for the 256 x 128 plain / bias kernels: the finished tile parked as packed bf16 in 32 registers and sent out
+// one 16-row pass per ring turn from inside the NEXT tile's K loop (LDS write, read-back and stores in three different
+// K steps, vmcnt waits widened by the two stores in flight; 233 VGPRs, no spills, results bit-identical): -5 % at
+// N = 768 for K = 768 and K = 3072 alike — the block-wide barrier after every K step turns whatever one wave adds
+// to a step into a delay for all eight, and the added branches cost the loop more than the 2 us epilogue it hides.)
 template <typename TO>
 __device__ __forceinline__ void stage_flush(const unsigned char* reg, TO* __restrict__ C, int64_t ldc, int64_t row_g,
                                             int64_t col_g, int64_t M, int64_t N, int lane, int accumulate) {
