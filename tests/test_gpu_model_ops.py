@@ -511,3 +511,40 @@ def test_optimizer_kernels():
         assert_close(vd, v, 1e-5, 1e-9)
         assert_close(ed, ema, 1e-5, 1e-6)
         assert torch.equal(pb, pd.bfloat16())
+
+
+def test_baseline_size_properties_attention_and_gemm():
+    """Size-independent properties at BASELINE sizes (where the CPU oracle would take minutes): attention at the cfg-2 /
+    cfg-5 shapes with V = 1 returns exactly 1 and is exactly linear in V; the big-tile GEMMs at the cfg-2 MLP shape are
+    exactly linear under power-of-two scaling, agree between the NT form and the NN form on a transposed copy of the
+    weight, and the weight-gradient (TN) form equals the NT product of the transposed operands."""
+    ops = _ops()
+    torch.manual_seed(7)
+    for B, H, L, d in ((64, 12, 512, 64), (32, 12, 1024, 64)):
+        qkv = torch.randn(B, L, 3, H, d, device=DEV, dtype=torch.bfloat16)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        o, lse = ops.attn_fwd(q, k, v)
+        assert bool(torch.isfinite(lse).all())
+        qkv1 = qkv.clone()
+        qkv1[:, :, 2] = 1.0
+        o1, _ = ops.attn_fwd(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2])
+        assert torch.equal(o1, torch.ones_like(o1)), "softmax rows must sum to one"
+        qkv2 = qkv.clone()
+        qkv2[:, :, 2] *= 2
+        o2, _ = ops.attn_fwd(qkv2[:, :, 0], qkv2[:, :, 1], qkv2[:, :, 2])
+        assert torch.equal(o2.float(), o.float() * 2), "attention is linear in V"
+        # every output is a convex combination of the values of its head
+        vmax = v.float().amax(dim=1, keepdim=True)
+        vmin = v.float().amin(dim=1, keepdim=True)
+        assert bool(((o.float() <= vmax + 1e-2) & (o.float() >= vmin - 1e-2)).all())
+    M, D, F = 64 * 512, 768, 3072
+    x = torch.randn(M, D, device=DEV).bfloat16()
+    W = (torch.randn(F, D, device=DEV) * 0.05).bfloat16()
+    y = ops.gemm_nt(x, W)
+    assert torch.equal(ops.gemm_nt(x, (W.float() * 4).bfloat16()).float(), y.float() * 4)
+    Wt = W.t().contiguous()                       # [D, F]: the NN form multiplies by B as stored
+    assert rel_err(ops.gemm_nn(x, Wt), y) < 1e-6   # same products, same fp32 accumulation order per K tile
+    g = torch.randn(M, F, device=DEV).bfloat16()
+    dW = ops.gemm_tn(g, x, out_dtype=torch.float32)            # [F, D] = g^T x
+    ref = ops.gemm_nt(g.t().contiguous(), x.t().contiguous(), out_dtype=torch.float32)
+    assert rel_err(dW, ref) < 1e-5                # (split-K changes the fp32 summation order)
