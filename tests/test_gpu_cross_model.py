@@ -91,7 +91,7 @@ def test_g11_cross_model(golden):
     loss_q3.backward()
     for k, p in model.named_parameters():
         ref = g["joint_grad." + k]
-        assert_close(p.grad, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-7, k)
+        assert_close(p.grad, ref, 1e-4, 1e-4 * float(ref.abs().max()) + 1e-7, k)
     model.eval()
     with torch.no_grad():
         assert_close(model(protein_indices=pt, timesteps=sigma, mode="protein_only"), g["prot_only_logits"], 1e-4, 2e-4)
