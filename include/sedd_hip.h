@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEDD_ABI_VERSION 2
+#define SEDD_ABI_VERSION 3
 
 typedef void* sedd_stream_t; /* hipStream_t */
 
@@ -110,8 +110,12 @@ int sedd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, sedd_st
 int sedd_embedding_fwd(const float* table, const int64_t* idx, float* out, int64_t M, int D, int V,
                        sedd_stream_t stream);
 /* dtable[idx[r]] += dout[r] (dtable fp32 [V, D], accumulated into). */
-int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t M, int D, int V,
+int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, float* ws, int64_t M, int D, int V,
                        sedd_stream_t stream);
+/* ws: NULL, or fp32 scratch of sedd_embedding_bwd_ws_floats(M, D, V) floats: where that is non-zero (V <= 32, the protein
+ * vocabulary) every 512-row block writes its partial table there and a fixed-order fold adds them to dtable
+ * (bit-reproducible); otherwise, and with NULL, the blocks add with fp32 atomics. */
+int64_t sedd_embedding_bwd_ws_floats(int64_t M, int D, int V);
 
 /* LayerNorm (transformer.py:30-38, fp32, eps 1e-5, scale w, no bias) fused with modulate_fused
  * (fused_add_dropout_scale.py:33-34): y = LN(x)*w*(1+scale_b)+shift_b.  x fp32 [M, D]; shift/scale are rows of
@@ -205,8 +209,10 @@ int sedd_logits_epilogue(void* logits, int dtype, const float* sigma, const int6
 /* its backward: dlogits[r, idx[r]] = 0 in place. */
 int sedd_logits_epilogue_bwd(void* dlogits, int dtype, const int64_t* idx, int64_t M, int V, sedd_stream_t stream);
 
-/* Column sums: out[j] (+)= sum_r a[r, j]  (bias gradients); a [M, N] with row stride lda; out fp32 [N]. */
-int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, int accumulate, int64_t M, int N,
+/* Column sums: out[j] (+)= sum_r a[r, j]  (bias gradients); a [M, N] with row stride lda; out fp32 [N].  ws: NULL, or fp32
+ * scratch of ceil(M / 128) * N floats — the 128-row blocks then write their partial sums there and a fixed-order fold adds
+ * them to out (bit-reproducible); with NULL they add to out with fp32 atomics. */
+int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, float* ws, int accumulate, int64_t M, int N,
                 sedd_stream_t stream);
 /* out[N, M] = a[M, N]^T with optional dtype conversion (operand re-layout for the wgrad/dgrad GEMMs). */
 int sedd_transpose(const void* a, int a_dtype, int64_t lda, void* out, int out_dtype, int64_t ldo, int64_t M,
@@ -228,14 +234,24 @@ int sedd_scale_(void* x, int dtype, const float* scale, int64_t n, sedd_stream_t
 int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
                  int64_t K, sedd_stream_t stream);
+/* sedd_gemm_nt with a caller-owned workspace (16-byte aligned, may be NULL): accumulating fp32 outputs of small shapes
+ * (one or a few output tiles, a long reduction: the adaLN conditioning gradient, the [V, D] output-layer weight
+ * gradient) split K over blocks; with workspace_bytes >= 4 * slices * M * N (slices <= 64) the slices park their partial
+ * tiles there and a fixed-order fold adds them to C — bit-reproducible run to run — instead of adding to C with fp32
+ * atomics.  Everything else as sedd_gemm_nt. */
+int sedd_gemm_nt_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                    int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
+                    int64_t K, void* workspace, int64_t workspace_bytes, sedd_stream_t stream);
 /* Data gradient of Linear -> GELU(tanh) in one launch (autograd of the MLP nn.Sequential(Linear, GELU, Linear),
  * transformer.py:129-133): C[M,N] = (A[M,K] * B[N,K]^T) .* gelu_tanh'(pre[M,N]) with A = dY of the second Linear,
  * B = its weight transposed [in, out], pre = the saved pre-activation (row stride ldc, dtype of C); colsum (fp32 [N],
  * may be NULL) receives += the column sums of C, i.e. the bias gradient of the first Linear.  bf16 only, M >= 192,
  * N >= 96, N % 8 == 0, K % 32 == 0, 16-byte aligned C / pre rows; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then use
- * sedd_gemm_nt + sedd_gelu_bwd + sedd_colsum). */
+ * sedd_gemm_nt + sedd_gelu_bwd + sedd_colsum).  colsum_ws: NULL, or fp32 [ceil(M/256), N] scratch — each row tile then
+ * writes its column sums to its own row and a fixed-order fold adds them to colsum (bit-reproducible run to run); with
+ * NULL the row tiles add to colsum with fp32 atomics (sum order varies). */
 int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
-                       int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
+                       int out_dtype, const void* pre, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
 /* The QKV projection with the rotary position embedding applied in the GEMM epilogue (transformer.py:165-171: attn_qkv,
  * rearrange 'b s (three h d) -> b s three h d', rotary.apply_rotary_pos_emb): C = packed qkv [M, 3*H*d] = A[M,K] *
@@ -255,7 +271,7 @@ int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
 /* sedd_gemm_nt_dgelu with B given as [K, N] (the second MLP weight as stored, transformer.py:132):
  * C = (A[M,K] * B[K,N]) .* gelu_tanh'(pre[M,N]); colsum += column sums of C.  Same requirements as sedd_gemm_nn. */
 int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
-                       int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N, int64_t K,
+                       int out_dtype, const void* pre, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and

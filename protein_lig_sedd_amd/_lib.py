@@ -33,7 +33,7 @@ SIGNATURES = {
     "sedd_silu_fwd": "pplp",
     "sedd_silu_bwd": "ppplp",
     "sedd_embedding_fwd": "pppliip",
-    "sedd_embedding_bwd": "pppliip",
+    "sedd_embedding_bwd": "ppppliip",
     "sedd_ln_modulate_fwd": "pppppilpippllip",
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_gate": "pipppilppppp" + "pp" + "flf" + "pp" + "llip",
@@ -48,16 +48,17 @@ SIGNATURES = {
     "sedd_gelu_bwd": "pppilp",
     "sedd_logits_epilogue": "pippillip",
     "sedd_logits_epilogue_bwd": "piplip",
-    "sedd_colsum": "pilpilip",
+    "sedd_colsum": "pilppilip",
     "sedd_transpose": "pilpilllp",
     "sedd_cast": "pipilp",
     "sedd_scale_": "piplp",
     "sedd_gemm_nt": "plplpliipipilllp",
+    "sedd_gemm_nt_ws": "plplpliipipilllplp",
     "sedd_gemm_tn": "plplpliiilllplp",
-    "sedd_gemm_nt_dgelu": "plplpliipplllp",
+    "sedd_gemm_nt_dgelu": "plplpliippplllp",
     "sedd_gemm_nn": "plplpliipilllp",
     "sedd_gemm_nt_rotary": "plplpliipippiiilllp",
-    "sedd_gemm_nn_dgelu": "plplpliipplllp",
+    "sedd_gemm_nn_dgelu": "plplpliippplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",
     "sedd_attn_varlen_fwd": "pppppp" + "iiiiii" + "lll" + "p",
@@ -93,6 +94,8 @@ def lib():
         fn.restype = ctypes.c_int
     L.sedd_ln_bwd_chunks.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.sedd_ln_bwd_chunks.restype = ctypes.c_int64
+    L.sedd_embedding_bwd_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    L.sedd_embedding_bwd_ws_floats.restype = ctypes.c_int64
     _lib = L
     return L
 

@@ -928,9 +928,12 @@ __global__ void __launch_bounds__(TPB) embedding_bwd_small_kernel(const float* _
 // V <= 32 (the protein vocabulary): 512 rows x 256 columns per block, every wave into its OWN [V][256] LDS slice with
 // plain read-add-write (a slice address is touched by one lane only, in program order: no LDS atomics, which ran the
 // kernel at 0.8 TB/s), 16 bytes of a row per lane; the four slices are folded on the way out.
+// ws != NULL: the block's [V, 256-column] partial table goes to ws[blockIdx.y] (every entry written, zeros included) and
+// embedding_fold_kernel adds the row blocks up in order — bit-reproducible; ws == NULL: fp32 atomics into dtable.
 __global__ void __launch_bounds__(TPB) embedding_bwd_v32_kernel(const float* __restrict__ dout,
                                                                 const int64_t* __restrict__ idx,
-                                                                float* __restrict__ dtable, int64_t M, int D, int V) {
+                                                                float* __restrict__ dtable, int64_t M, int D, int V,
+                                                                float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float acc[(TPB / 64) * 32 * 256];
     const int lane = threadIdx.x & 63, rr = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -951,8 +954,18 @@ __global__ void __launch_bounds__(TPB) embedding_bwd_v32_kernel(const float* __r
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < TPB / 64; ++w) sum += acc[w * V * 256 + i];
-        if (col < D && sum != 0.f) atomicAdd(dtable + (int64_t)(i >> 8) * D + col, sum);
+        if (col >= D) continue;
+        if (ws) ws[((int64_t)blockIdx.y * V + (i >> 8)) * D + col] = sum;
+        else if (sum != 0.f) atomicAdd(dtable + (int64_t)(i >> 8) * D + col, sum);
     }
+}
+__global__ void __launch_bounds__(TPB) embedding_fold_kernel(const float* __restrict__ ws, int nblk, int64_t VD,
+                                                             float* __restrict__ dtable) {
+    const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= VD) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[(int64_t)b * VD + e];
+    dtable[e] += s;
 }
 __global__ void __launch_bounds__(TPB) embedding_bwd_large_kernel(const float* __restrict__ dout,
                                                                   const int64_t* __restrict__ idx,
@@ -962,15 +975,25 @@ __global__ void __launch_bounds__(TPB) embedding_bwd_large_kernel(const float* _
         atomicAdd(dtable + idx[row] * D + (i % D), dout[i]);
     }
 }
-extern "C" int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t M, int D, int V,
+extern "C" int64_t sedd_embedding_bwd_ws_floats(int64_t M, int D, int V) {
+    return (V <= 32 && D % 4 == 0) ? ((M + EMB_ROWS - 1) / EMB_ROWS) * (int64_t)V * D : 0;
+}
+extern "C" int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, float* ws, int64_t M, int D, int V,
                                   sedd_stream_t stream) {
     SEDD_CHECK_ARG(M >= 0 && D > 0 && V > 0, "embedding_bwd: bad sizes");
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(dout && idx && dtable, "embedding_bwd: null pointer");
-    if (V <= 32 && D % 4 == 0 && ((uintptr_t)dout & 15) == 0)
-        hipLaunchKernelGGL(embedding_bwd_v32_kernel, dim3((D + 255) / 256, (unsigned)((M + EMB_ROWS - 1) / EMB_ROWS)),
-                           dim3(TPB), 0, (hipStream_t)stream, dout, idx, dtable, M, D, V);
-    else if (V <= 64)
+    if (V <= 32 && D % 4 == 0 && ((uintptr_t)dout & 15) == 0) {
+        const int nblk = (int)((M + EMB_ROWS - 1) / EMB_ROWS);
+        hipLaunchKernelGGL(embedding_bwd_v32_kernel, dim3((D + 255) / 256, (unsigned)nblk), dim3(TPB), 0,
+                           (hipStream_t)stream, dout, idx, dtable, M, D, V, ws);
+        if (ws) {
+            SEDD_LAUNCH_CHECK();
+            const int64_t VD = (int64_t)V * D;
+            hipLaunchKernelGGL(embedding_fold_kernel, dim3((unsigned)((VD + TPB - 1) / TPB)), dim3(TPB), 0,
+                               (hipStream_t)stream, ws, nblk, VD, dtable);
+        }
+    } else if (V <= 64)
         hipLaunchKernelGGL(embedding_bwd_small_kernel, dim3((D + 63) / 64, (unsigned)((M + EMB_ROWS - 1) / EMB_ROWS)),
                            dim3(TPB), 0, (hipStream_t)stream, dout, idx, dtable, M, D, V);
     else
@@ -1091,7 +1114,7 @@ extern "C" int sedd_logits_epilogue_bwd(void* dlogits, int dtype, const int64_t*
 #define CS_ROWS 128
 template <typename T>
 __global__ void __launch_bounds__(TPB) colsum_kernel(const T* __restrict__ a, int64_t lda, float* __restrict__ out,
-                                                     int64_t M, int N) {
+                                                     int64_t M, int N, float* __restrict__ ws) {
     __shared__ float red[(TPB / 64) * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -1103,10 +1126,19 @@ __global__ void __launch_bounds__(TPB) colsum_kernel(const T* __restrict__ a, in
     __syncthreads();
     if (wave == 0 && c < N) {
         for (int wv = 1; wv < TPB / 64; ++wv) s += red[wv * 64 + lane];
-        atomicAdd(out + c, s);
+        if (ws) ws[(int64_t)blockIdx.y * N + c] = s;  // (folded in row-block order by colsum_rows_fold_kernel)
+        else atomicAdd(out + c, s);
     }
 }
-extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, int accumulate, int64_t M, int N,
+__global__ void __launch_bounds__(TPB) colsum_rows_fold_kernel(const float* __restrict__ ws, int nblk, int N,
+                                                               float* __restrict__ out) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += ws[(int64_t)b * N + c];
+    out[c] += s;
+}
+extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, float* ws, int accumulate, int64_t M, int N,
                            sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(dtype), "colsum: bad dtype");
     SEDD_CHECK_ARG(M >= 0 && N > 0 && lda >= N, "colsum: bad sizes");
@@ -1118,7 +1150,12 @@ extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, in
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(a, "colsum: a is null");
     const dim3 grid((N + 63) / 64, (unsigned)((M + CS_ROWS - 1) / CS_ROWS));
-    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(TPB), 0, st, (const T*)a, lda, out, M, N));
+    if (grid.y == 1) ws = nullptr;  // one row block: nothing to order
+    DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(TPB), 0, st, (const T*)a, lda, out, M, N, ws));
+    if (ws) {
+        SEDD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_rows_fold_kernel, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, st, ws, (int)grid.y, N, out);
+    }
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }

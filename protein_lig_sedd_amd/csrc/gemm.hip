@@ -213,7 +213,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_glds_kernel(const bf16_t* __
                                                                 TO* __restrict__ C, int64_t ldc,
                                                                 const float* __restrict__ bias, int epi,
                                                                 TO* __restrict__ pre, int accumulate, int64_t M,
-                                                                int64_t N, int64_t Kper, int ntn) {
+                                                                int64_t N, int64_t Kper, int ntn,
+                                                                float* __restrict__ slabs = nullptr) {
     __shared__ __attribute__((aligned(16))) uint4 smem[2][2][BM * 8];  // [buffer][A|B][row*8 + swizzled chunk] 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,7 +268,23 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_glds_kernel(const bf16_t* __
         }
     }
 #undef STAGE
+    if constexpr (sizeof(TO) == 4) {
+        if (slabs) {  // split K with a workspace: this slice's partial tile, plain stores; splitk_fold_kernel adds the slices
+            store_tile<float>(slabs + (int64_t)blockIdx.y * M * N, N, nullptr, nullptr, SEDD_EPI_NONE, 0, 0, m0, n0, wr,
+                              wc, lane, M, N, acc);
+            return;
+        }
+    }
     store_tile<TO>(C, ldc, pre, bias, epi, accumulate, gridDim.y > 1, m0, n0, wr, wc, lane, M, N, acc);
+}
+// C[m][n] += slab[0][m][n] + slab[1][m][n] + ... (slice order): the deterministic form of the split-K above
+__global__ void __launch_bounds__(256) splitk_fold_kernel(const float* __restrict__ slabs, int nslices, int64_t M,
+                                                          int64_t N, float* __restrict__ C, int64_t ldc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * N) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += slabs[(int64_t)k * M * N + e];
+    C[(e / N) * ldc + e % N] += s;
 }
 
 
@@ -770,7 +787,12 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         for (int w = 0; w < WM; ++w)
                             t += reinterpret_cast<const float*>(stage_lds + (w * WN + wn) * SC::REGION)[lane];
                         const int64_t c = col_w + lane;
-                        if (c < N) atomicAdd(colsum + c, t);
+                        // with a workspace (it rides in `slabs`, which split-K never uses here): this row tile's sums
+                        // go to their own row of it and a fixed-order fold adds them up (bit-reproducible); else atomics
+                        if (c < N) {
+                            if (slabs) reinterpret_cast<float*>(slabs)[(row_t / BIG_BM) * N + c] = t;
+                            else atomicAdd(colsum + c, t);
+                        }
                     }
                 }
             } else {
@@ -1090,10 +1112,21 @@ static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
 
 static const RotArgs kNoRot{nullptr, nullptr, 1, 0};
 
+// colsum[c] += ws[0][c] + ws[1][c] + ... in row order (the dGELU epilogue's per-row-tile column sums): fixed order, no atomics
+__global__ void __launch_bounds__(256) colsum_fold_kernel(const float* __restrict__ ws, int ntm, int64_t N,
+                                                          float* __restrict__ colsum) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int t = 0; t < ntm; ++t) s += ws[(int64_t)t * N + c];
+    colsum[c] += s;
+}
+
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                         int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
                         int64_t K, float* colsum, sedd_stream_t stream, bool b_kn = false,
-                        const RotArgs* rot = nullptr) {
+                        const RotArgs* rot = nullptr, float* colsum_ws = nullptr, float* sk_ws = nullptr,
+                        int64_t sk_ws_bytes = 0) {
     SEDD_CHECK_ARG((in_dtype == SEDD_F32 || in_dtype == SEDD_BF16) && (out_dtype == SEDD_F32 || out_dtype == SEDD_BF16),
                    "gemm_nt: bad dtype");
     if (b_kn) {  // B given as [K, N] (NN form): bf16 big-tile kernel only
@@ -1162,7 +1195,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
 #define BIG_LAUNCH_X(BN_, DG_, NNB_)                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, BN_, 4, false, DG_, 8, NNB_>), g2, dim3(512), 0, st,            \
                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre,   \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum, kNoRot)
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)(DG_ ? colsum_ws : nullptr),   \
+                       colsum, kNoRot)
             if (rot) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, false, 8, false, true>), g2, dim3(512), 0,
                                        st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
@@ -1175,12 +1209,12 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 256, 4, false, true>), g2, dim3(512), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)nullptr, colsum, kNoRot);
+                                       (float4*)colsum_ws, colsum, kNoRot);
             } else if (epilogue == EPI_DGELU) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, true>), g2, dim3(512), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)nullptr, colsum, kNoRot);
+                                       (float4*)colsum_ws, colsum, kNoRot);
             } else if (out_dtype == SEDD_BF16) {
                 static const int nw4 = getenv("SEDD_GEMM_NW4") ? atoi(getenv("SEDD_GEMM_NW4")) : 0;
                 if (nw4 && splitk == 1 && (nw4 == 2 || !wide)) {
@@ -1199,6 +1233,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             }
 #undef BIG_LAUNCH
 #undef BIG_LAUNCH_X
+            if (epilogue == EPI_DGELU && colsum && colsum_ws) {
+                SEDD_LAUNCH_CHECK();
+                hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, colsum_ws,
+                                   (int)tm, N, colsum);
+            }
         } else if (K % BK16 == 0) {
             // split K across blockIdx.y for accumulating fp32 outputs with too few tiles to fill 256 CUs
             int splitk = 1;
@@ -1211,10 +1250,19 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                 hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<bf16_t>), g2, dim3(256), 0, st, (const bf16_t*)A, lda,
                                    (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre, accumulate,
                                    M, N, K / splitk, (int)ntn);
-            else
+            else {
+                // with a large enough workspace the K slices park their partial tiles and a fixed-order fold adds them
+                // to C (bit-reproducible); without one they add to C with fp32 atomics
+                float* slabs = splitk > 1 && sk_ws && sk_ws_bytes >= (int64_t)splitk * M * N * 4 ? sk_ws : nullptr;
                 hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<float>), g2, dim3(256), 0, st, (const bf16_t*)A, lda,
                                    (const bf16_t*)B, ldb, (float*)C, ldc, bias, epilogue, (float*)pre, accumulate, M,
-                                   N, K / splitk, (int)ntn);
+                                   N, K / splitk, (int)ntn, slabs);
+                if (slabs) {
+                    SEDD_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, slabs,
+                                       splitk, M, N, (float*)C, ldc);
+                }
+            }
         } else if (out_dtype == SEDD_BF16)
             hipLaunchKernelGGL((gemm_bf16_nt_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A, lda,
                                (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre, accumulate, M, N,
@@ -1245,14 +1293,26 @@ extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t l
                         stream);
 }
 
+// sedd_gemm_nt with a caller-owned workspace for the launches that split K over blocks (accumulating fp32 outputs of
+// small shapes: one or a few output tiles and a long reduction)
+extern "C" int sedd_gemm_nt_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
+                               int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                               sedd_stream_t stream) {
+    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU, "gemm_nt_ws: bad epilogue %d", epilogue);
+    SEDD_CHECK_ARG(workspace_bytes >= 0 && (!workspace || ((uintptr_t)workspace & 15) == 0), "gemm_nt_ws: bad workspace");
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, pre, accumulate, M, N, K, nullptr,
+                        stream, false, nullptr, nullptr, (float*)workspace, workspace_bytes);
+}
+
 // C[M,N] = (A[M,K] * B[N,K]^T) .* gelu_tanh'(pre[M,N]); colsum[N] += column sums of C (optional).  The data gradient of
 // Linear -> GELU in one launch (autograd of nn.Sequential(Linear, GELU(tanh), Linear), transformer.py:129-133).
 extern "C" int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                  int in_dtype, int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N,
-                                  int64_t K, sedd_stream_t stream) {
+                                  int in_dtype, int out_dtype, const void* pre, float* colsum, float* colsum_ws,
+                                  int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
     SEDD_CHECK_ARG(pre, "gemm_nt_dgelu: pre is null");
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
-                        K, colsum, stream);
+                        K, colsum, stream, false, nullptr, colsum_ws);
 }
 
 // The QKV projection with the rotary position embedding applied in the epilogue (transformer.py:165-171: attn_qkv,
@@ -1287,11 +1347,11 @@ extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t l
 
 // sedd_gemm_nt_dgelu with B given as [K, N]: dU = (dY W2) .* gelu'(U), colsum += column sums, W2 [out, hidden] as stored
 extern "C" int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                  int in_dtype, int out_dtype, const void* pre, float* colsum, int64_t M, int64_t N,
-                                  int64_t K, sedd_stream_t stream) {
+                                  int in_dtype, int out_dtype, const void* pre, float* colsum, float* colsum_ws,
+                                  int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
     SEDD_CHECK_ARG(pre, "gemm_nn_dgelu: pre is null");
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
-                        K, colsum, stream, true);
+                        K, colsum, stream, true, nullptr, colsum_ws);
 }
 
 // C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations

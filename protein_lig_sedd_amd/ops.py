@@ -287,7 +287,17 @@ def embedding_bwd(dout, idx, dtable):
     """dtable[idx] += dout (in place on dtable, fp32 [V, D])."""
     idx, dout = _c(idx, torch.int64), _c(dout, torch.float32)
     V, D = dtable.shape
-    check(lib().sedd_embedding_bwd(_p(dout), _p(idx), _p(dtable), idx.numel(), D, V, _stream()), "sedd_embedding_bwd")
+    need = lib().sedd_embedding_bwd_ws_floats(idx.numel(), D, V)  # fixed-order fold instead of atomics where supported
+    ws = None
+    if need:
+        ws = _EMB_WS.get(dtable.device.index)
+        if ws is None or ws.numel() < need:
+            ws = _EMB_WS[dtable.device.index] = torch.empty(need, dtype=torch.float32, device=dtable.device)
+    check(lib().sedd_embedding_bwd(_p(dout), _p(idx), _p(dtable), _p(ws), idx.numel(), D, V, _stream()),
+          "sedd_embedding_bwd")
+
+
+_EMB_WS = {}
 
 
 def _mod_args(t):
@@ -477,13 +487,23 @@ def logits_epilogue_bwd_(dlogits, idx):
     return dlogits
 
 
+_COLSUM_ROWS_WS = {}
+
+
 def colsum(a, out=None, accumulate=False):
     """a [M, N] (row stride allowed) -> fp32 [N]; accumulate into `out` when given and accumulate=True."""
     M, N = a.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=a.device)
         accumulate = False
-    check(lib().sedd_colsum(_p(a), _dt(a), a.stride(0), _p(out), 1 if accumulate else 0, M, N, _stream()), "sedd_colsum")
+    ws = None
+    if M > 128:  # several row blocks: fixed-order fold out of a scratch instead of atomics
+        need = ((M + 127) // 128) * N
+        ws = _COLSUM_ROWS_WS.get(a.device.index)
+        if ws is None or ws.numel() < need:
+            ws = _COLSUM_ROWS_WS[a.device.index] = torch.empty(need, dtype=torch.float32, device=a.device)
+    check(lib().sedd_colsum(_p(a), _dt(a), a.stride(0), _p(out), _p(ws), 1 if accumulate else 0, M, N, _stream()),
+          "sedd_colsum")
     return out
 
 
@@ -520,9 +540,33 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
-        check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                                 _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
+        if accumulate and out.dtype == torch.float32 and A.dtype == torch.bfloat16:
+            # launches that split K (small outputs, long reductions) fold their slices in a fixed order out of the
+            # split-K scratch instead of adding to `out` with atomics
+            ws = _tn_workspace(A.device)
+            check(lib().sedd_gemm_nt_ws(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                        _p(bias), epi, _p(pre), 1, M, N, K, _p(ws), ws.numel() * 4, _stream()),
+                  "sedd_gemm_nt_ws")
+        else:
+            check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                     _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
     return (out, pre) if (gelu and want_pre) else out
+
+
+_COLSUM_WS = {}
+
+
+def _colsum_ws(like, M, N, colsum):
+    """per-device fp32 scratch [ceil(M/256), N] for the dGELU epilogue's column sums (fixed-order fold instead of atomics);
+    consecutive launches on a stream reuse it (the fold that reads it is ordered before the next launch)."""
+    if colsum is None:
+        return None
+    need = ((M + 255) // 256) * N
+    key = like.device.index
+    ws = _COLSUM_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _COLSUM_WS[key] = torch.empty(need, dtype=torch.float32, device=like.device)
+    return ws
 
 
 def gemm_nt_dgelu_supported(A, B, pre):
@@ -545,7 +589,8 @@ def gemm_nt_dgelu(A, B, pre, colsum=None):
     out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
         check(lib().sedd_gemm_nt_dgelu(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                                       _p(pre), _p(colsum), M, N, K, _stream()), "sedd_gemm_nt_dgelu")
+                                       _p(pre), _p(colsum), _p(_colsum_ws(A, M, N, colsum)), M, N, K, _stream()),
+              "sedd_gemm_nt_dgelu")
     return out
 
 
@@ -609,7 +654,8 @@ def gemm_nn_dgelu(A, B, pre, colsum=None):
     out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
         check(lib().sedd_gemm_nn_dgelu(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                                       _p(pre), _p(colsum), M, N, K, _stream()), "sedd_gemm_nn_dgelu")
+                                       _p(pre), _p(colsum), _p(_colsum_ws(A, M, N, colsum)), M, N, K, _stream()),
+              "sedd_gemm_nn_dgelu")
     return out
 
 

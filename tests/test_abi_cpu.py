@@ -41,13 +41,13 @@ def test_header_symbols_exported_and_signatures_match():
     assert len(protos) >= 35
     for name, (ret, sig) in protos.items():
         assert hasattr(L, name), f"libsedd_hip.so does not export {name}"
-        if name in ("sedd_abi_version", "sedd_last_error", "sedd_ln_bwd_chunks"):
+        if name in ("sedd_abi_version", "sedd_last_error", "sedd_ln_bwd_chunks", "sedd_embedding_bwd_ws_floats"):
             continue
         assert name in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {name}"
         assert _lib.SIGNATURES[name] == sig, f"{name}: ctypes '{_lib.SIGNATURES[name]}' vs header '{sig}'"
     for name in _lib.SIGNATURES:
         assert name in protos, f"{name} bound in _lib.py but not declared in the header"
-    assert L.sedd_abi_version() == 2
+    assert L.sedd_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():

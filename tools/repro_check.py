@@ -34,12 +34,19 @@ def run():
         x0 = torch.randint(0, cfg.tokens, (B, L), device=dev)
         losses.append(float(tr.train_step(x0)))
     torch.cuda.synchronize()
+    global LAYOUT
+    LAYOUT = [(off, p.numel(), n) for (n, p), off in zip(model.named_parameters(), tr.flat.offsets)]
     return losses, {k: v.detach().clone() for k, v in model.named_parameters()}, tr.flat.g.clone()
 
 la, pa, ga = run()
 lb, pb, gb = run()
 print("losses", la, lb, "equal" if la == lb else "DIFFER")
 bad = [(k, float((pa[k] - pb[k]).abs().max())) for k in pa if not torch.equal(pa[k], pb[k])]
-print(f"{len(bad)} of {len(pa)} parameter tensors differ bitwise; last-step gradient buffers equal: {torch.equal(ga, gb)}")
+neq = (ga != gb)
+print(f"{len(bad)} of {len(pa)} parameter tensors differ bitwise; last-step gradient buffers equal: {torch.equal(ga, gb)}"
+      f" ({int(neq.sum())} of {ga.numel()} elements differ, nan {int(torch.isnan(ga).sum())}; first at {int(neq.nonzero()[0]) if bool(neq.any()) else -1})")
+for i in (neq.nonzero().flatten().tolist()[:8] if bool(neq.any()) else []):
+    own = [(n, i - off, num) for off, num, n in LAYOUT if off <= i < off + num]
+    print(f"   grad element {i}: {own or 'padding'}  {float(ga[i]):.6e} vs {float(gb[i]):.6e}")
 for k, d in bad[:40]:
     print(f"   {k}: max |diff| {d:.3e}")
