@@ -1130,13 +1130,19 @@ __global__ void __launch_bounds__(TPB) colsum_kernel(const T* __restrict__ a, in
         else atomicAdd(out + c, s);
     }
 }
+// out[c] += sum over the row blocks b of ws[b][c], fixed order: one block per 4 columns, 64 contiguous ranges of row blocks
+// per column (N is small where this runs — the [M, V] logits gradient — and the row blocks are many), xor-tree combine
 __global__ void __launch_bounds__(TPB) colsum_rows_fold_kernel(const float* __restrict__ ws, int nblk, int N,
                                                                float* __restrict__ out) {
-    const int c = blockIdx.x * TPB + threadIdx.x;
-    if (c >= N) return;
+    static_assert(TPB == 256, "4 columns x 64 ranges");
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per = (nblk + 63) / 64, b0 = lane * per, b1 = b0 + per < nblk ? b0 + per : nblk;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += ws[(int64_t)b * N + c];
-    out[c] += s;
+    if (c < N)
+        for (int b = b0; b < b1; ++b) s += ws[(int64_t)b * N + c];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0 && c < N) out[c] += s;
 }
 extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, float* ws, int accumulate, int64_t M, int N,
                            sedd_stream_t stream) {
@@ -1154,7 +1160,7 @@ extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, fl
     DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(TPB), 0, st, (const T*)a, lda, out, M, N, ws));
     if (ws) {
         SEDD_LAUNCH_CHECK();
-        hipLaunchKernelGGL(colsum_rows_fold_kernel, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, st, ws, (int)grid.y, N, out);
+        hipLaunchKernelGGL(colsum_rows_fold_kernel, dim3((N + 3) / 4), dim3(TPB), 0, st, ws, (int)grid.y, N, out);
     }
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;

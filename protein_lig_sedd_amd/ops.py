@@ -289,7 +289,7 @@ def embedding_bwd(dout, idx, dtable):
     V, D = dtable.shape
     need = lib().sedd_embedding_bwd_ws_floats(idx.numel(), D, V)  # fixed-order fold instead of atomics where supported
     ws = None
-    if need:
+    if need and not _ATOMIC:
         ws = _EMB_WS.get(dtable.device.index)
         if ws is None or ws.numel() < need:
             ws = _EMB_WS[dtable.device.index] = torch.empty(need, dtype=torch.float32, device=dtable.device)
@@ -497,7 +497,7 @@ def colsum(a, out=None, accumulate=False):
         out = torch.empty(N, dtype=torch.float32, device=a.device)
         accumulate = False
     ws = None
-    if M > 128:  # several row blocks: fixed-order fold out of a scratch instead of atomics
+    if M > 128 and not _ATOMIC:  # several row blocks: fixed-order fold out of a scratch instead of atomics
         need = ((M + 127) // 128) * N
         ws = _COLSUM_ROWS_WS.get(a.device.index)
         if ws is None or ws.numel() < need:
@@ -540,7 +540,7 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
-        if accumulate and out.dtype == torch.float32 and A.dtype == torch.bfloat16:
+        if accumulate and out.dtype == torch.float32 and A.dtype == torch.bfloat16 and not _ATOMIC:
             # launches that split K (small outputs, long reductions) fold their slices in a fixed order out of the
             # split-K scratch instead of adding to `out` with atomics
             ws = _tn_workspace(A.device)
@@ -554,12 +554,14 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
 
 
 _COLSUM_WS = {}
+# SEDD_ATOMIC_REDUCTIONS=1: no scratches for the cross-tile sums (fp32 atomics instead of fixed-order folds) — an A/B knob
+_ATOMIC = bool(os.environ.get("SEDD_ATOMIC_REDUCTIONS"))
 
 
 def _colsum_ws(like, M, N, colsum):
     """per-device fp32 scratch [ceil(M/256), N] for the dGELU epilogue's column sums (fixed-order fold instead of atomics);
     consecutive launches on a stream reuse it (the fold that reads it is ordered before the next launch)."""
-    if colsum is None:
+    if colsum is None or _ATOMIC:
         return None
     need = ((M + 255) // 256) * N
     key = like.device.index
