@@ -114,7 +114,8 @@ int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, flo
                        sedd_stream_t stream);
 /* ws: NULL, or fp32 scratch of sedd_embedding_bwd_ws_floats(M, D, V) floats: where that is non-zero (V <= 32, the protein
  * vocabulary) every 512-row block writes its partial table there and a fixed-order fold adds them to dtable
- * (bit-reproducible); otherwise, and with NULL, the blocks add with fp32 atomics. */
+ * (bit-reproducible).  Shapes with V * M <= 2^22 (the cross model's tables) are summed by an owner-computes kernel in row
+ * order, also bit-reproducible and without scratch; everything else adds with fp32 atomics. */
 int64_t sedd_embedding_bwd_ws_floats(int64_t M, int D, int V);
 
 /* LayerNorm (transformer.py:30-38, fp32, eps 1e-5, scale w, no bias) fused with modulate_fused
