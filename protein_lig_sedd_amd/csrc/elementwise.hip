@@ -394,11 +394,27 @@ __global__ void __launch_bounds__(TPB) chunk_reduce_kernel(const float* __restri
     for (int k = 0; k < nplanes; ++k) {
         if (!outs[k] || !((vec_mask >> k) & 1)) continue;
         float4 a = f4(0.f);
-        if (col < D)
-            for (int64_t c = rg; c < nchunk; c += 16) {
-                const float4 v = load4<float>(ws + ((int64_t)k * nchunk + c) * D + col);
+        if (col < D) {
+            // four running sums per row group (chunks c, c+16, c+32, c+48 in flight together: the walk is a chain of
+            // dependent load latencies otherwise), combined in a fixed order
+            float4 a1 = f4(0.f), a2 = f4(0.f), a3 = f4(0.f);
+            const float* base = ws + (int64_t)k * nchunk * D + col;
+            int64_t c = rg;
+            for (; c + 48 < nchunk; c += 64) {
+                const float4 v0 = load4<float>(base + c * D), v1 = load4<float>(base + (c + 16) * D);
+                const float4 v2 = load4<float>(base + (c + 32) * D), v3 = load4<float>(base + (c + 48) * D);
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; c < nchunk; c += 16) {
+                const float4 v = load4<float>(base + c * D);
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
+            a.x = (a.x + a1.x) + (a2.x + a3.x); a.y = (a.y + a1.y) + (a2.y + a3.y);
+            a.z = (a.z + a1.z) + (a2.z + a3.z); a.w = (a.w + a1.w) + (a2.w + a3.w);
+        }
         red[rg][threadIdx.x & 15] = a;
         __syncthreads();
         if (threadIdx.x < 16 && col < D) {
