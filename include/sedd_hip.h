@@ -265,8 +265,9 @@ int sedd_gemm_nt_rotary(const void* A, int64_t lda, const void* B, int64_t ldb, 
 /* Data gradient of nn.Linear against the weight AS STORED (dX = dY W with W [out_features, in_features] row-major; the
  * reference gets it from torch.nn.functional.linear's backward, e.g. for transformer.py:125-133's Linears):
  * C[M,N] = A[M,K] * B[K,N] (+ bias[N] for SEDD_EPI_BIAS) — "NN": B's reduction index is the row, so no transposed
- * weight copy is made.  bf16 in/out only; M >= 192, N >= 96, K % 32 == 0, N % 8 == 0, lda/ldb multiples of 8,
- * 16-byte aligned bases; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then transpose + sedd_gemm_nt). */
+ * weight copy is made.  bf16 in/out: M >= 192, N >= 96, K % 32 == 0, N % 8 == 0, lda/ldb multiples of 8; fp32 in/out
+ * (the exact-fp32 MFMA kernel of sedd_gemm_nt reading B k-major): any M, K % 4 == 0, N % 4 == 0, lda/ldb multiples
+ * of 4; 16-byte aligned bases; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then transpose + sedd_gemm_nt). */
 int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K, sedd_stream_t stream);
 /* sedd_gemm_nt_dgelu with B given as [K, N] (the second MLP weight as stored, transformer.py:132):
@@ -277,13 +278,16 @@ int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
  * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no
- * transposed copies are made.  bf16 operands only, fp32 accumulation, C fp32 or bf16; accumulate != 0 adds into an
+ * transposed copies are made.  bf16 operands (fp32 operands: last paragraph), fp32 accumulation, C fp32 or bf16; accumulate != 0 adds into an
  * fp32 C (the flat gradient buffer).  An output with too few 256-wide tiles for the chip is split along K: with a
  * caller-owned `workspace` (16-byte aligned, workspace_bytes >= 256 MiB always suffices; exactly
  * slices * tiles * 256 * tile_width * 4 with slices * tiles <= 256) the slices park fp32 partial tiles there and a
  * second launch sums them into C; with workspace == NULL an accumulating call falls back to fp32 atomics.
  * Requirements: K % 32 == 0, M % 8 == 0, N % 8 == 0, lda % 8 == 0, ldb % 8 == 0, 16-byte aligned bases; otherwise
- * SEDD_ERR_UNSUPPORTED_SHAPE (callers fall back to sedd_transpose + sedd_gemm_nt). */
+ * SEDD_ERR_UNSUPPORTED_SHAPE (callers fall back to sedd_transpose + sedd_gemm_nt).
+ * fp32 operands (fp32 C): the exact-fp32 MFMA kernel reading both operands k-major as stored; any K, M % 4 == 0,
+ * N % 4 == 0, lda % 4 == 0, ldb % 4 == 0; an output of fewer than 128 tiles of 64 x 64 is split along K when the
+ * workspace holds slices * M * N floats (fixed-order fold, bit-reproducible), and not split otherwise. */
 int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
                  int64_t workspace_bytes, sedd_stream_t stream);

@@ -279,12 +279,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_glds_kernel(const bf16_t* __
 }
 // C[m][n] += slab[0][m][n] + slab[1][m][n] + ... (slice order): the deterministic form of the split-K above
 __global__ void __launch_bounds__(256) splitk_fold_kernel(const float* __restrict__ slabs, int nslices, int64_t M,
-                                                          int64_t N, float* __restrict__ C, int64_t ldc) {
+                                                          int64_t N, float* __restrict__ C, int64_t ldc,
+                                                          int accumulate = 1) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= M * N) return;
     float s = 0.f;
     for (int k = 0; k < nslices; ++k) s += slabs[(int64_t)k * M * N + e];
-    C[(e / N) * ldc + e % N] += s;
+    float* c = C + (e / N) * ldc + e % N;
+    *c = accumulate ? *c + s : s;
 }
 
 
@@ -949,8 +951,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ fp32
-#define BK32 16
-#define LDK32 17  // padded row (floats): conflict-free ds_read_b32 column reads
+#define F32_BK 32
 template <typename TO>
 __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* __restrict__ pre,
                                           const float* __restrict__ bias, int epi, int accumulate, int64_t row,
@@ -967,85 +968,117 @@ __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* _
     *p = from_f32<TO>(v);
 }
 
-template <typename TO>
-__global__ void __launch_bounds__(256) gemm_f32_nt_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const float* __restrict__ B, int64_t ldb,
-                                                          TO* __restrict__ C, int64_t ldc,
-                                                          const float* __restrict__ bias, int epi,
-                                                          TO* __restrict__ pre, int accumulate, int64_t M, int64_t N,
-                                                          int64_t K, int ntn) {
-    __shared__ float sA[BM * LDK32];
-    __shared__ float sB[BN * LDK32];
+// C[M,N] = A * B^T over exact-fp32 MFMA (32x32x2: the products of one output are summed in ascending k, an fmaf chain).
+// Operand layouts are template flags, so the data-gradient (B stored [K, N]) and weight-gradient (A stored [K, M],
+// B stored [K, N]) products of nn.Linear read the row-major activations and weights as they are, without transposed copies:
+//   AKM = false: A[i][k] at A[i * lda + k]      AKM = true: at A[k * lda + i]   (likewise BKM for B[j][k])
+// Block = 4 waves as 2 x 2, wave tile (TM*32) x (TN*32) -> block tile (TM*64) x (TN*64); the host picks 128x128, 128x64
+// or 64x64 by how many tiles the output gives the 256 CUs.  K step 32: the next step's global loads are issued into
+// registers before the MFMA loop of the current one and stored to LDS after it.  LDS holds a tile k-major
+// ([32][rows (+1)]): operand reads (lane -> row) are consecutive words; a row-major source is scattered in as scalars
+// (the odd row stride spreads the 8 k-chunks of a wave over all banks), a k-major source as whole float4.
+// gridDim.y > 1 splits K: slice y covers [y * kper, (y + 1) * kper) and parks its partial tile in `slabs`
+// (splitk_fold_kernel adds the slices in order).
+template <typename TO, int TM, int TN, bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int64_t ldb, TO* __restrict__ C,
+                                                       int64_t ldc, const float* __restrict__ bias, int epi,
+                                                       TO* __restrict__ pre, int accumulate, int64_t M, int64_t N,
+                                                       int64_t K, int64_t kper, int ntn, float* __restrict__ slabs) {
+    constexpr int RA = TM * 64, RB = TN * 64;                      // rows of the block's A / B tiles
+    constexpr int SA = RA + (AKM ? 0 : 1), SB = RB + (BKM ? 0 : 1);  // LDS row strides (floats)
+    constexpr int NA = RA / 32, NB = RB / 32;                      // float4 chunks per thread and K step
+    __shared__ __align__(16) float sA[F32_BK * SA];
+    __shared__ __align__(16) float sB[F32_BK * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(wg / ntn) * BM, n0 = (int64_t)(wg % ntn) * BN;
+    const int64_t m0 = (int64_t)(wg / ntn) * RA, n0 = (int64_t)(wg % ntn) * RB;
+    const int64_t kbeg = (int64_t)blockIdx.y * kper, kend = kbeg + kper < K ? kbeg + kper : K;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int64_t nkt = (K + BK32 - 1) / BK32;
-    for (int64_t kt = 0; kt < nkt; ++kt) {
-        float4 ra0, ra1, rb0, rb1;
-#define GLOAD(i, ra, rb)                                                                 \
-        {                                                                                \
-            const int chunk = tid + 256 * (i), row = chunk >> 2, kc = chunk & 3;         \
-            const int64_t k = kt * BK32 + kc * 4;                                        \
-            int64_t ar = m0 + row, br = n0 + row;                                        \
-            ar = ar < M ? ar : M - 1;                                                    \
-            br = br < N ? br : N - 1;                                                    \
-            ra = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
-            rb = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
-            if (k < K) {                                                                 \
-                ra = *reinterpret_cast<const float4*>(A + ar * lda + k);                 \
-                rb = *reinterpret_cast<const float4*>(B + br * ldb + k);                 \
-            }                                                                            \
-        }
-        GLOAD(0, ra0, rb0) GLOAD(1, ra1, rb1)
-#undef GLOAD
+    float4 ra[NA], rb[NB];
+    // one K step of an operand tile, global -> registers.  Rows past the edge are clamped (their products are never
+    // stored), k past the end of the slice reads as zero.
+#define F32_GLOAD(R_, KM_, NCH, P, ld, r0, ext, reg, k0)                                        \
+    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                           \
+        const int c = tid + 256 * i;                                                            \
+        reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                               \
+        if (KM_) {                                                                              \
+            const int kk = c / (R_ / 4), r4 = c % (R_ / 4);                                     \
+            int64_t row = r0 + r4 * 4;                                                          \
+            row = row < ext ? row : ext - 4;                                                    \
+            if (k0 + kk < kend) reg[i] = *reinterpret_cast<const float4*>(P + (k0 + kk) * ld + row); \
+        } else {                                                                                \
+            const int row_ = c >> 3, kc = c & 7;                                                \
+            int64_t row = r0 + row_;                                                            \
+            row = row < ext ? row : ext - 1;                                                    \
+            if (k0 + kc * 4 < kend) reg[i] = *reinterpret_cast<const float4*>(P + row * ld + k0 + kc * 4); \
+        }                                                                                       \
+    }
+#define F32_LSTORE(R_, S_, KM_, NCH, sX, reg)                                                   \
+    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                           \
+        const int c = tid + 256 * i;                                                            \
+        if (KM_) {                                                                              \
+            const int kk = c / (R_ / 4), r4 = c % (R_ / 4);                                     \
+            *reinterpret_cast<float4*>(sX + kk * S_ + r4 * 4) = reg[i];                         \
+        } else {                                                                                \
+            const int row_ = c >> 3, kc = c & 7;                                                \
+            float* p = sX + (kc * 4) * S_ + row_;                                               \
+            p[0] = reg[i].x; p[S_] = reg[i].y; p[2 * S_] = reg[i].z; p[3 * S_] = reg[i].w;      \
+        }                                                                                       \
+    }
+    F32_GLOAD(RA, AKM, NA, A, lda, m0, M, ra, kbeg)
+    F32_GLOAD(RB, BKM, NB, B, ldb, n0, N, rb, kbeg)
+    for (int64_t k0 = kbeg; k0 < kend; k0 += F32_BK) {
+        F32_LSTORE(RA, SA, AKM, NA, sA, ra)
+        F32_LSTORE(RB, SB, BKM, NB, sB, rb)
         __syncthreads();
-#define LSTORE(i, ra, rb)                                                          \
-        {                                                                          \
-            const int chunk = tid + 256 * (i), row = chunk >> 2, kc = chunk & 3;   \
-            float* pa = sA + row * LDK32 + kc * 4;                                 \
-            float* pb = sB + row * LDK32 + kc * 4;                                 \
-            pa[0] = ra.x; pa[1] = ra.y; pa[2] = ra.z; pa[3] = ra.w;                \
-            pb[0] = rb.x; pb[1] = rb.y; pb[2] = rb.z; pb[3] = rb.w;                \
+        if (k0 + F32_BK < kend) {
+            F32_GLOAD(RA, AKM, NA, A, lda, m0, M, ra, k0 + F32_BK)
+            F32_GLOAD(RB, BKM, NB, B, ldb, n0, N, rb, k0 + F32_BK)
         }
-        LSTORE(0, ra0, rb0) LSTORE(1, ra1, rb1)
-#undef LSTORE
-        __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < BK32 / 2; ++ks) {
+        for (int ks = 0; ks < F32_BK / 2; ++ks) {
             // 32x32x2: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
             const int k = ks * 2 + (lane >> 5);
-            float a[2], b[2];
+            float a[TM], b[TN];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = sA[(wr * 64 + m * 32 + (lane & 31)) * LDK32 + k];
+            for (int m = 0; m < TM; ++m) a[m] = sA[k * SA + wr * (TM * 32) + m * 32 + (lane & 31)];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = sB[(wc * 64 + n * 32 + (lane & 31)) * LDK32 + k];
+            for (int n = 0; n < TN; ++n) b[n] = sB[k * SB + wc * (TN * 32) + n * 32 + (lane & 31)];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < TN; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
         }
+        __syncthreads();
     }
+#undef F32_GLOAD
+#undef F32_LSTORE
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                epilogue1<TO>(C, ldc, pre, bias, epi, accumulate,
-                              m0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5),
-                              n0 + wc * 64 + n * 32 + (lane & 31), M, N, acc[m][n][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * (TM * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t col = n0 + wc * (TN * 32) + n * 32 + (lane & 31);
+                if (slabs) {
+                    if (row < M && col < N) slabs[((int64_t)blockIdx.y * M + row) * N + col] = acc[m][n][r];
+                } else {
+                    epilogue1<TO>(C, ldc, pre, bias, epi, accumulate, row, col, M, N, acc[m][n][r]);
+                }
+            }
 }
 
 
@@ -1135,6 +1168,58 @@ __global__ void __launch_bounds__(256) colsum_fold_kernel(const float* __restric
     part[p][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (p == 0 && c < N) colsum[c] += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+// fp32 products.  layout 0: A [M,K], B [N,K] (NT)   1: A [M,K], B [K,N] (NN)   2: A [K,M], B [K,N] (TN).
+// ws (optional, fp32 output without epilogue only): scratch for splitting K when even 64 x 64 tiles leave CUs idle.
+static int gemm_f32_launch(int layout, const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc,
+                           int out_dtype, const float* bias, int epi, void* pre, int accumulate, int64_t M, int64_t N,
+                           int64_t K, float* ws, int64_t ws_bytes, hipStream_t st) {
+    // tile shape: fewest chip-wide rounds x tile work, the smaller tiles priced a little above their flops
+    static const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+    static const double price[3] = {1.0, 1.06, 1.15};
+    int best = 0;
+    double best_cost = 0;
+    int64_t best_tiles = 0;
+    for (int c = 0; c < 3; ++c) {
+        const int64_t bm = cand[c][0] * 64, bn = cand[c][1] * 64;
+        const int64_t t = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+        const double cost = (double)((t + 255) / 256) * (double)(bm * bn) * price[c];
+        if (c == 0 || cost < best_cost) { best = c; best_cost = cost; best_tiles = t; }
+    }
+    const int64_t bn = cand[best][1] * 64, ntn = (N + bn - 1) / bn;
+    SEDD_CHECK_ARG(best_tiles < (1LL << 31), "gemm (fp32): too many tiles");
+    int splitk = 1;
+    int64_t kper = (K + F32_BK - 1) / F32_BK * F32_BK;
+    if (best == 2 && ws && out_dtype == SEDD_F32 && epi == SEDD_EPI_NONE) {
+        // every slice keeps >= 8 K steps; slices x tiles stay within two blocks per CU
+        while (best_tiles * splitk * 2 <= 512 && kper % (2 * F32_BK) == 0 && kper / 2 >= 8 * F32_BK &&
+               (int64_t)splitk * 2 * M * N * 4 <= ws_bytes)
+            { splitk *= 2; kper /= 2; }
+    }
+    float* slabs = splitk > 1 ? ws : nullptr;
+    const dim3 grid((unsigned)best_tiles, (unsigned)splitk);
+#define F32_LAUNCH(TO, TM, TN, AKM, BKM)                                                                              \
+    hipLaunchKernelGGL((gemm_f32_kernel<TO, TM, TN, AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, (TO*)C, ldc,  \
+                       bias, epi, (TO*)pre, accumulate, M, N, K, kper, (int)ntn, slabs)
+#define F32_TILES(TO, AKM, BKM)                                                                                       \
+    { if (best == 0) F32_LAUNCH(TO, 2, 2, AKM, BKM); else if (best == 1) F32_LAUNCH(TO, 2, 1, AKM, BKM);              \
+      else F32_LAUNCH(TO, 1, 1, AKM, BKM); }
+    if (out_dtype == SEDD_BF16) {  // (fp32 operands, bf16 result: NT only)
+        if (layout != 0) { sedd_set_error("gemm (fp32 operands): bf16 output only in the NT form"); return SEDD_ERR_UNSUPPORTED_SHAPE; }
+        F32_TILES(bf16_t, false, false)
+    } else if (layout == 0) F32_TILES(float, false, false)
+    else if (layout == 1) F32_TILES(float, false, true)
+    else F32_TILES(float, true, true)
+#undef F32_TILES
+#undef F32_LAUNCH
+    SEDD_LAUNCH_CHECK();
+    if (slabs) {
+        hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, slabs, splitk, M,
+                           N, (float*)C, ldc, accumulate);
+        SEDD_LAUNCH_CHECK();
+    }
+    return SEDD_OK;
 }
 
 static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
@@ -1287,14 +1372,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                                (const bf16_t*)B, ldb, (float*)C, ldc, bias, epilogue, (float*)pre, accumulate, M, N, K,
                                (int)ntn);
     } else {
-        if (out_dtype == SEDD_BF16)
-            hipLaunchKernelGGL((gemm_f32_nt_kernel<bf16_t>), grid, dim3(256), 0, st, (const float*)A, lda,
-                               (const float*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre, accumulate, M, N, K,
-                               (int)ntn);
-        else
-            hipLaunchKernelGGL((gemm_f32_nt_kernel<float>), grid, dim3(256), 0, st, (const float*)A, lda,
-                               (const float*)B, ldb, (float*)C, ldc, bias, epilogue, (float*)pre, accumulate, M, N, K,
-                               (int)ntn);
+        return gemm_f32_launch(0, (const float*)A, lda, (const float*)B, ldb, C, ldc, out_dtype, bias, epilogue, pre,
+                               accumulate, M, N, K, sk_ws, sk_ws_bytes, st);
     }
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
@@ -1356,6 +1435,21 @@ extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t l
                             int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K,
                             sedd_stream_t stream) {
     SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == SEDD_EPI_BIAS, "gemm_nn: bad epilogue %d", epilogue);
+    if (in_dtype == SEDD_F32) {  // exact-fp32 MFMA kernel reading B as stored
+        SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_nn: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+        SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || bias, "gemm_nn: epilogue needs a bias");
+        if (out_dtype != SEDD_F32 || K % 4 || N % 4 || lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+            lda < K || ldb < N || ldc < N) {
+            sedd_set_error("gemm_nn (fp32): unsupported operands (fp32 out; K %% 4, N %% 4, lda %% 4, ldb %% 4 must be 0, "
+                           "16-byte aligned bases): M=%ld N=%ld K=%ld lda=%ld ldb=%ld", (long)M, (long)N, (long)K,
+                           (long)lda, (long)ldb);
+            return SEDD_ERR_UNSUPPORTED_SHAPE;
+        }
+        if (M == 0 || N == 0) return SEDD_OK;
+        SEDD_CHECK_ARG(A && B && C, "gemm_nn: null pointer");
+        return gemm_f32_launch(1, (const float*)A, lda, (const float*)B, ldb, C, ldc, out_dtype, bias, epilogue, nullptr,
+                               0, M, N, K, nullptr, 0, (hipStream_t)stream);
+    }
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, nullptr, 0, M, N, K, nullptr, stream,
                         true);
 }
@@ -1376,6 +1470,21 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
                             int64_t workspace_bytes, sedd_stream_t stream) {
     SEDD_CHECK_ARG(out_dtype == SEDD_F32 || out_dtype == SEDD_BF16, "gemm_tn: bad dtype");
     SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_tn: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    if (in_dtype == SEDD_F32) {  // exact-fp32 MFMA kernel, both operands read k-major as stored; any K
+        if (out_dtype != SEDD_F32 || M % 4 || N % 4 || lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+            lda < M || ldb < N || ldc < N) {
+            sedd_set_error("gemm_tn (fp32): unsupported operands (fp32 out; M %% 4, N %% 4, lda %% 4, ldb %% 4 must be 0, "
+                           "16-byte aligned bases): M=%ld N=%ld K=%ld lda=%ld ldb=%ld", (long)M, (long)N, (long)K,
+                           (long)lda, (long)ldb);
+            return SEDD_ERR_UNSUPPORTED_SHAPE;
+        }
+        if (M == 0 || N == 0) return SEDD_OK;
+        SEDD_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
+        const bool ws_ok = workspace && ((uintptr_t)workspace & 15) == 0;
+        return gemm_f32_launch(2, (const float*)A, lda, (const float*)B, ldb, C, ldc, out_dtype, nullptr, SEDD_EPI_NONE,
+                               nullptr, accumulate, M, N, K, ws_ok ? (float*)workspace : nullptr,
+                               ws_ok ? workspace_bytes : 0, (hipStream_t)stream);
+    }
     if (in_dtype != SEDD_BF16 || K % BIG_BK || M % 8 || N % 8 || lda % 8 || ldb % 8 || ((uintptr_t)A & 15) ||
         ((uintptr_t)B & 15) || lda < M || ldb < N || ldc < N) {
         sedd_set_error("gemm_tn: unsupported operands (bf16 only; K %% 32, M %% 8, N %% 8, lda %% 8, ldb %% 8 must be 0, "

@@ -540,7 +540,7 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
-        if accumulate and out.dtype == torch.float32 and A.dtype == torch.bfloat16 and not _ATOMIC:
+        if accumulate and out.dtype == torch.float32 and not _ATOMIC:
             # launches that split K (small outputs, long reductions) fold their slices in a fixed order out of the
             # split-K scratch instead of adding to `out` with atomics
             ws = _tn_workspace(A.device)
@@ -627,13 +627,16 @@ def gemm_nn_supported(A, B):
         return False
     M, K = A.shape
     N = B.shape[1]
+    if A.dtype == torch.float32 and B.dtype == torch.float32:  # exact-fp32 MFMA kernel, any M
+        return (N % 4 == 0 and K % 4 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 4 == 0
+                and B.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
     return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and M >= 192 and N >= 96 and N % 8 == 0
             and K % 32 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
             and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 
 def gemm_nn(A, B, bias=None, out=None):
-    """C[M,N] = A[M,K] @ B[K,N] (+bias), bf16: the data gradient dY @ W against the weight as stored."""
+    """C[M,N] = A[M,K] @ B[K,N] (+bias), bf16 or fp32: the data gradient dY @ W against the weight as stored."""
     M, K = A.shape
     K2, N = B.shape
     if K != K2:
@@ -641,7 +644,7 @@ def gemm_nn(A, B, bias=None, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     epi = _L.EPI_NONE if bias is None else _L.EPI_BIAS
-    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+    with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
         check(lib().sedd_gemm_nn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                  _p(bias), epi, M, N, K, _stream()), "sedd_gemm_nn")
     return out
@@ -665,6 +668,9 @@ def gemm_tn_supported(A, B):
     """whether sedd_gemm_tn takes these operands (else: transpose + gemm_nt)."""
     K, M = A.shape
     N = B.shape[1]
+    if A.dtype == torch.float32 and B.dtype == torch.float32:  # exact-fp32 MFMA kernel, any K
+        return (M % 4 == 0 and N % 4 == 0 and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 4 == 0
+                and B.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
     return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 32 == 0 and M % 8 == 0 and N % 8 == 0
             and A.stride(1) == 1 and B.stride(1) == 1 and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0
             and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
@@ -684,7 +690,8 @@ def _tn_workspace(device):
 
 
 def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):
-    """C[M,N] (+)= A[K,M]^T @ B[K,N] (weight gradient: A = dY [tokens, out], B = X [tokens, in]); bf16 operands."""
+    """C[M,N] (+)= A[K,M]^T @ B[K,N] (weight gradient: A = dY [tokens, out], B = X [tokens, in]); bf16 or fp32
+    operands (fp32: fp32 C only)."""
     K, M = A.shape
     K2, N = B.shape
     if K != K2 or A.dtype != B.dtype:
@@ -693,7 +700,7 @@ def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):
         out = torch.empty(M, N, dtype=out_dtype or torch.float32, device=A.device)
         accumulate = False
     ws = _tn_workspace(A.device) if out.dtype == torch.float32 else None
-    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+    with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
         check(lib().sedd_gemm_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                  1 if accumulate else 0, M, N, K, _p(ws), 0 if ws is None else ws.numel() * 4,
                                  _stream()), "sedd_gemm_tn")
