@@ -53,13 +53,27 @@ def part_fwd(x2d, W, b, r0, r1, out_dtype=None):
 
 def part_bwd(x2d, dy2d, W, b, r0, r1, gW, gb, need_dx=True, dx_dtype=None):
     """accumulate dW[r0:r1] += dy^T x, db[r0:r1] += colsum(dy); return dx = dy @ W[r0:r1] (or None)."""
-    align = 8 if dy2d.dtype == torch.bfloat16 else 4
-    ops.gemm_nt(transpose_padded(dy2d, align), transpose_padded(x2d, align), out=gW[r0:r1], accumulate=True)
+    if ops.gemm_tn_supported(dy2d, x2d):  # straight from the row-major activations
+        ops.gemm_tn(dy2d, x2d, out=gW[r0:r1], accumulate=True)
+    else:
+        align = 8 if dy2d.dtype == torch.bfloat16 else 4
+        ops.gemm_nt(transpose_padded(dy2d, align), transpose_padded(x2d, align), out=gW[r0:r1], accumulate=True)
     if gb is not None:
         ops.colsum(dy2d, out=gb[r0:r1], accumulate=True)
     if not need_dx:
         return None
+    return part_dgrad(dy2d, W, r0, r1, dx_dtype=dx_dtype)
+
+
+def part_dgrad(dy2d, W, r0, r1, out=None, dx_dtype=None):
+    """dx = dy @ W[r0:r1]: against the weight rows as stored when the NN kernel takes the operands, else against the
+    cached transposed copy."""
+    Wc = compute_weight(W, dy2d.dtype)[r0:r1]
+    if dx_dtype in (None, dy2d.dtype) and (out is None or out.dtype == dy2d.dtype) and ops.gemm_nn_supported(dy2d, Wc):
+        return ops.gemm_nn(dy2d, Wc, out=out)
     Wt = compute_weight(W, dy2d.dtype, transposed=True)  # [K, Np]
+    if out is not None:
+        return ops.gemm_nt(dy2d, Wt[:, r0:r1], out=out)
     return ops.gemm_nt(dy2d, Wt[:, r0:r1], out_dtype=dx_dtype)
 
 
@@ -188,12 +202,8 @@ def cross_block_backward(dx2, st, P, n_heads):
     dq2 = dqkv.view(M, 3, D)
     for slot, dp in enumerate((dpq, dpk, dpv)):
         r0 = slot * D
-        align = 8 if cdt == torch.bfloat16 else 4
-        dpm = dp.view(M, D)
-        ops.gemm_nt(transpose_padded(dpm, align), transpose_padded(qkv2[:, slot], align), out=gWi[r0:r0 + D], accumulate=True)
-        ops.colsum(dpm, out=gbi[r0:r0 + D], accumulate=True)
-        Wt = compute_weight(Wi, cdt, transposed=True)
-        ops.gemm_nt(dpm, Wt[:, r0:r0 + D], out=dq2[:, slot])
+        part_bwd(qkv2[:, slot], dp.view(M, D), Wi, bi, r0, r0 + D, gWi, gbi, need_dx=False)
+        part_dgrad(dp.view(M, D), Wi, r0, r0 + D, out=dq2[:, slot])
     ops.rotary_qkv_(dqkv, st["cos"], st["sin"], conj=True)
     dh1 = part_bwd(st["h1"].view(M, D), dqkv.view(M, 3 * D), P["attn_qkv.weight"], P["attn_qkv.bias"], 0, 3 * D,
                    G("attn_qkv.weight"), G("attn_qkv.bias"))
