@@ -335,6 +335,14 @@ int sedd_attn_varlen_bwd(const void* q, const void* k, const void* v, const void
 int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                         const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int decoupled, int step, float ema_decay, int64_t n, sedd_stream_t stream);
+/* The dual-track trainer's iteration advances the optimiser TWICE on the same clipped gradients
+ * (training/run_train_protlig_cross_att.py:247 `scaler.step(optimizer)` inside optimize_fn, then :325
+ * `optimizer.step()`), the EMA update (:248) falling between the two.  One pass over the buffers doing both:
+ * bit-identical to sedd_adamw_ema_step(step, ema_decay) followed by sedd_adamw_ema_step(step + 1, ema_decay = 1). */
+int sedd_adamw_ema_double_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                               const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
+                               sedd_stream_t stream);
 /* out[0] = sum_r w[r / L] * x[r]  (losses.py:29: (dsigma[:, None] * loss).mean() with w_b = dsigma_b / M).
  * fp32, deterministic two-stage; ws fp32 [1024] caller workspace. */
 int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L, float* ws, float* out,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sedd_attn_varlen_fwd": "pppppp" + "iiiiii" + "lll" + "p",
     "sedd_attn_varlen_bwd": "pppppp" + "pppp" + "p" + "iiiiii" + "lll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
+    "sedd_adamw_ema_double_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
     "sedd_sumsq_clip": "plffppp",
     "sedd_ema_update": "ppflp",
     "sedd_batch_weighted_sum": "ppllppp",

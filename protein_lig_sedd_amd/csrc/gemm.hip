@@ -951,7 +951,6 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ fp32
-#define F32_BK 32
 template <typename TO>
 __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* __restrict__ pre,
                                           const float* __restrict__ bias, int epi, int accumulate, int64_t row,
@@ -973,13 +972,13 @@ __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* _
 // B stored [K, N]) products of nn.Linear read the row-major activations and weights as they are, without transposed copies:
 //   AKM = false: A[i][k] at A[i * lda + k]      AKM = true: at A[k * lda + i]   (likewise BKM for B[j][k])
 // Block = 4 waves as 2 x 2, wave tile (TM*32) x (TN*32) -> block tile (TM*64) x (TN*64); the host picks 128x128, 128x64
-// or 64x64 by how many tiles the output gives the 256 CUs.  K step 32: the next step's global loads are issued into
+// or 64x64 by how many tiles the output gives the 256 CUs.  K step BK: the next step's global loads are issued into
 // registers before the MFMA loop of the current one and stored to LDS after it.  LDS holds a tile k-major
-// ([32][rows (+1)]): operand reads (lane -> row) are consecutive words; a row-major source is scattered in as scalars
+// ([BK][rows (+1)]): operand reads (lane -> row) are consecutive words; a row-major source is scattered in as scalars
 // (the odd row stride spreads the 8 k-chunks of a wave over all banks), a k-major source as whole float4.
 // gridDim.y > 1 splits K: slice y covers [y * kper, (y + 1) * kper) and parks its partial tile in `slabs`
 // (splitk_fold_kernel adds the slices in order).
-template <typename TO, int TM, int TN, bool AKM, bool BKM>
+template <typename TO, int TM, int TN, bool AKM, bool BKM, int BK>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb, TO* __restrict__ C,
                                                        int64_t ldc, const float* __restrict__ bias, int epi,
@@ -987,9 +986,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
                                                        int64_t K, int64_t kper, int ntn, float* __restrict__ slabs) {
     constexpr int RA = TM * 64, RB = TN * 64;                      // rows of the block's A / B tiles
     constexpr int SA = RA + (AKM ? 0 : 1), SB = RB + (BKM ? 0 : 1);  // LDS row strides (floats)
-    constexpr int NA = RA / 32, NB = RB / 32;                      // float4 chunks per thread and K step
-    __shared__ __align__(16) float sA[F32_BK * SA];
-    __shared__ __align__(16) float sB[F32_BK * SB];
+    constexpr int NA = RA * BK / 1024, NB = RB * BK / 1024;        // float4 chunks per thread and K step
+    __shared__ __align__(16) float sA[BK * SA];
+    __shared__ __align__(16) float sB[BK * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -1017,7 +1016,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
             row = row < ext ? row : ext - 4;                                                    \
             if (k0 + kk < kend) reg[i] = *reinterpret_cast<const float4*>(P + (k0 + kk) * ld + row); \
         } else {                                                                                \
-            const int row_ = c >> 3, kc = c & 7;                                                \
+            const int row_ = c / (BK / 4), kc = c % (BK / 4);                                                \
             int64_t row = r0 + row_;                                                            \
             row = row < ext ? row : ext - 1;                                                    \
             if (k0 + kc * 4 < kend) reg[i] = *reinterpret_cast<const float4*>(P + row * ld + k0 + kc * 4); \
@@ -1030,36 +1029,49 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
             const int kk = c / (R_ / 4), r4 = c % (R_ / 4);                                     \
             *reinterpret_cast<float4*>(sX + kk * S_ + r4 * 4) = reg[i];                         \
         } else {                                                                                \
-            const int row_ = c >> 3, kc = c & 7;                                                \
+            const int row_ = c / (BK / 4), kc = c % (BK / 4);                                                \
             float* p = sX + (kc * 4) * S_ + row_;                                               \
             p[0] = reg[i].x; p[S_] = reg[i].y; p[2 * S_] = reg[i].z; p[3 * S_] = reg[i].w;      \
         }                                                                                       \
     }
     F32_GLOAD(RA, AKM, NA, A, lda, m0, M, ra, kbeg)
     F32_GLOAD(RB, BKM, NB, B, ldb, n0, N, rb, kbeg)
-    for (int64_t k0 = kbeg; k0 < kend; k0 += F32_BK) {
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         F32_LSTORE(RA, SA, AKM, NA, sA, ra)
         F32_LSTORE(RB, SB, BKM, NB, sB, rb)
         __syncthreads();
-        if (k0 + F32_BK < kend) {
-            F32_GLOAD(RA, AKM, NA, A, lda, m0, M, ra, k0 + F32_BK)
-            F32_GLOAD(RB, BKM, NB, B, ldb, n0, N, rb, k0 + F32_BK)
+        if (k0 + BK < kend) {
+            F32_GLOAD(RA, AKM, NA, A, lda, m0, M, ra, k0 + BK)
+            F32_GLOAD(RB, BKM, NB, B, ldb, n0, N, rb, k0 + BK)
         }
-#pragma unroll
-        for (int ks = 0; ks < F32_BK / 2; ++ks) {
-            // 32x32x2: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
-            const int k = ks * 2 + (lane >> 5);
-            float a[TM], b[TN];
-#pragma unroll
-            for (int m = 0; m < TM; ++m) a[m] = sA[k * SA + wr * (TM * 32) + m * 32 + (lane & 31)];
-#pragma unroll
-            for (int n = 0; n < TN; ++n) b[n] = sB[k * SB + wc * (TN * 32) + n * 32 + (lane & 31)];
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        // 32x32x2: lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].  Operands are read a group of
+        // G k-pairs ahead of the MFMAs that use them (the scheduler, left alone, reads each pair right before its use
+        // and every MFMA pair then waits a full LDS latency).
+        constexpr int G = 4, NG = BK / 2 / G;
+        float a[2][G][TM], b[2][G][TN];
+#define F32_LREAD(g, buf)                                                                        \
+        _Pragma("unroll") for (int q = 0; q < G; ++q) {                                          \
+            const int k = ((g) * G + q) * 2 + (lane >> 5);                                       \
+            _Pragma("unroll") for (int m = 0; m < TM; ++m)                                       \
+                a[buf][q][m] = sA[k * SA + wr * (TM * 32) + m * 32 + (lane & 31)];               \
+            _Pragma("unroll") for (int n = 0; n < TN; ++n)                                       \
+                b[buf][q][n] = sB[k * SB + wc * (TN * 32) + n * 32 + (lane & 31)];               \
         }
+        F32_LREAD(0, 0)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) F32_LREAD(g + 1, (g + 1) & 1)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][q][m], b[g & 1][q][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef F32_LREAD
         __syncthreads();
     }
 #undef F32_GLOAD
@@ -1187,24 +1199,31 @@ static int gemm_f32_launch(int layout, const float* A, int64_t lda, const float*
         const double cost = (double)((t + 255) / 256) * (double)(bm * bn) * price[c];
         if (c == 0 || cost < best_cost) { best = c; best_cost = cost; best_tiles = t; }
     }
+    static const int force = getenv("SEDD_F32_TILE") ? atoi(getenv("SEDD_F32_TILE")) : -1;  // tuning aid
+    if (force >= 0 && force < 3) {
+        best = force;
+        best_tiles = ((M + cand[best][0] * 64 - 1) / (cand[best][0] * 64)) * ((N + cand[best][1] * 64 - 1) / (cand[best][1] * 64));
+    }
     const int64_t bn = cand[best][1] * 64, ntn = (N + bn - 1) / bn;
     SEDD_CHECK_ARG(best_tiles < (1LL << 31), "gemm (fp32): too many tiles");
     int splitk = 1;
-    int64_t kper = (K + F32_BK - 1) / F32_BK * F32_BK;
+    // K step: 64 for the 64 x 64 tile (16 MFMAs per wave and step would not cover a global-load latency), else 32
+    const int bk = best == 2 ? 64 : 32;
+    int64_t kper = (K + bk - 1) / bk * bk;
     if (best == 2 && ws && out_dtype == SEDD_F32 && epi == SEDD_EPI_NONE) {
-        // every slice keeps >= 8 K steps; slices x tiles stay within two blocks per CU
-        while (best_tiles * splitk * 2 <= 512 && kper % (2 * F32_BK) == 0 && kper / 2 >= 8 * F32_BK &&
+        // every slice keeps >= 256 of K; slices x tiles stay within two blocks per CU
+        while (best_tiles * splitk * 2 <= 512 && kper % (2 * bk) == 0 && kper / 2 >= 256 &&
                (int64_t)splitk * 2 * M * N * 4 <= ws_bytes)
             { splitk *= 2; kper /= 2; }
     }
     float* slabs = splitk > 1 ? ws : nullptr;
     const dim3 grid((unsigned)best_tiles, (unsigned)splitk);
-#define F32_LAUNCH(TO, TM, TN, AKM, BKM)                                                                              \
-    hipLaunchKernelGGL((gemm_f32_kernel<TO, TM, TN, AKM, BKM>), grid, dim3(256), 0, st, A, lda, B, ldb, (TO*)C, ldc,  \
+#define F32_LAUNCH(TO, TM, TN, AKM, BKM, BK)                                                                          \
+    hipLaunchKernelGGL((gemm_f32_kernel<TO, TM, TN, AKM, BKM, BK>), grid, dim3(256), 0, st, A, lda, B, ldb, (TO*)C, ldc,  \
                        bias, epi, (TO*)pre, accumulate, M, N, K, kper, (int)ntn, slabs)
 #define F32_TILES(TO, AKM, BKM)                                                                                       \
-    { if (best == 0) F32_LAUNCH(TO, 2, 2, AKM, BKM); else if (best == 1) F32_LAUNCH(TO, 2, 1, AKM, BKM);              \
-      else F32_LAUNCH(TO, 1, 1, AKM, BKM); }
+    { if (best == 0) F32_LAUNCH(TO, 2, 2, AKM, BKM, 32); else if (best == 1) F32_LAUNCH(TO, 2, 1, AKM, BKM, 32);      \
+      else F32_LAUNCH(TO, 1, 1, AKM, BKM, 64); }
     if (out_dtype == SEDD_BF16) {  // (fp32 operands, bf16 result: NT only)
         if (layout != 0) { sedd_set_error("gemm (fp32 operands): bf16 output only in the NT form"); return SEDD_ERR_UNSUPPORTED_SHAPE; }
         F32_TILES(bf16_t, false, false)

@@ -6,12 +6,25 @@
 
 #define TPB 256
 
+// g * cs + l2 * p with the rounding points fixed (the product g * cs rounded, then one fma), so that the one- and the
+// two-step instantiations below cannot contract it differently
+__device__ __forceinline__ float l2_grad(float g, float cs, float l2, float p) {
+#pragma clang fp contract(off)
+    const float gs = g * cs;
+    return __builtin_fmaf(l2, p, gs);
+}
+
+// NS = 2: the step is applied twice on the same gradients with the bias corrections of `step` and `step + 1`, the EMA
+// taking the weights between the two (the dual-track trainer's optimize_fn + optimizer.step(), quirk Q2) — one pass over
+// the buffers instead of two, the same arithmetic per element in the same order.
+template <int NS>
 __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ ema, bf16_t* __restrict__ pb,
                                                         const float* __restrict__ clip, float gscale, float decay_mul,
                                                         float l2, float beta1, float beta2, float eps, float step_size,
-                                                        float inv_bc2_sqrt, float one_m_ema, int64_t n) {
+                                                        float inv_bc2_sqrt, float one_m_ema, int64_t n,
+                                                        float step_size2, float inv_bc2_sqrt2) {
     const float cs = (clip ? clip[0] : 1.0f) * gscale;
     const int64_t nv = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
@@ -19,25 +32,27 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
-        float* P = &pp.x; const float* G = &gg.x; float* Mm = &mm.x; float* Vv = &vv.x;
+        float4 ee = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ema) ee = reinterpret_cast<float4*>(ema)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* Mm = &mm.x; float* Vv = &vv.x; float* E = &ee.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = G[k] * cs + l2 * P[k];  // l2 != 0: torch.optim.Adam's weight decay (decay_mul is then 1)
-            P[k] *= decay_mul;
-            Mm[k] = Mm[k] * beta1 + gk * (1.0f - beta1);
-            Vv[k] = Vv[k] * beta2 + gk * gk * (1.0f - beta2);
-            const float denom = sqrtf(Vv[k]) * inv_bc2_sqrt + eps;
-            P[k] -= step_size * (Mm[k] / denom);
+        for (int s = 0; s < NS; ++s) {
+            const float ss = s == 0 ? step_size : step_size2, ib = s == 0 ? inv_bc2_sqrt : inv_bc2_sqrt2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = l2_grad(G[k], cs, l2, P[k]);  // l2 != 0: torch.optim.Adam's weight decay (decay_mul is then 1)
+                P[k] *= decay_mul;
+                Mm[k] = Mm[k] * beta1 + gk * (1.0f - beta1);
+                Vv[k] = Vv[k] * beta2 + gk * gk * (1.0f - beta2);
+                const float denom = sqrtf(Vv[k]) * ib + eps;
+                P[k] -= ss * (Mm[k] / denom);
+                if (s == 0) E[k] -= one_m_ema * (E[k] - P[k]);
+            }
         }
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
-        if (ema) {
-            float4 ee = reinterpret_cast<float4*>(ema)[i];
-            ee.x -= one_m_ema * (ee.x - pp.x); ee.y -= one_m_ema * (ee.y - pp.y);
-            ee.z -= one_m_ema * (ee.z - pp.z); ee.w -= one_m_ema * (ee.w - pp.w);
-            reinterpret_cast<float4*>(ema)[i] = ee;
-        }
+        if (ema) reinterpret_cast<float4*>(ema)[i] = ee;
         if (pb) {
             union { bf16_t h[4]; uint2 u; } c;
             c.h[0] = (bf16_t)pp.x; c.h[1] = (bf16_t)pp.y; c.h[2] = (bf16_t)pp.z; c.h[3] = (bf16_t)pp.w;
@@ -46,10 +61,10 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
     }
 }
 
-extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
-                                   const float* clip_coef, float grad_scale, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
-                                   sedd_stream_t stream) {
+static int adamw_ema_launch(int ns, float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                            const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
+                            sedd_stream_t stream) {
     SEDD_CHECK_ARG(n >= 0 && step >= 1, "adamw_ema_step: bad n=%ld step=%d", (long)n, step);
     if (n % 4 != 0) {
         sedd_set_error("adamw_ema_step: n=%ld must be a multiple of 4 (pad the flat buffer)", (long)n);
@@ -57,16 +72,43 @@ extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v,
     }
     if (n == 0) return SEDD_OK;
     SEDD_CHECK_ARG(p && g && m && v, "adamw_ema_step: null pointer");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    float step_size[2], inv_bc2_sqrt[2];
+    for (int s = 0; s < 2; ++s) {
+        const double bc1 = 1.0 - pow((double)beta1, step + s), bc2 = 1.0 - pow((double)beta2, step + s);
+        step_size[s] = (float)((double)lr / bc1);
+        inv_bc2_sqrt[s] = (float)(1.0 / sqrt(bc2));
+    }
     const float decay_mul = decoupled ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
     const float l2 = decoupled ? 0.0f : weight_decay;
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3(sedd_grid_for(n / 4, TPB, 256 * 16)), dim3(TPB), 0, (hipStream_t)stream,
-                       p, g, m, v, ema, (bf16_t*)p_bf16, clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size,
-                       inv_bc2_sqrt, 1.0f - ema_decay, n);
+    const dim3 grid(sedd_grid_for(n / 4, TPB, 256 * 16));
+    if (ns == 1)
+        hipLaunchKernelGGL(adamw_ema_kernel<1>, grid, dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)p_bf16,
+                           clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size[0], inv_bc2_sqrt[0],
+                           1.0f - ema_decay, n, 0.f, 0.f);
+    else
+        hipLaunchKernelGGL(adamw_ema_kernel<2>, grid, dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)p_bf16,
+                           clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size[0], inv_bc2_sqrt[0],
+                           1.0f - ema_decay, n, step_size[1], inv_bc2_sqrt[1]);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
+}
+
+extern "C" int sedd_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                                   const float* clip_coef, float grad_scale, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
+                                   sedd_stream_t stream) {
+    return adamw_ema_launch(1, p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay,
+                            decoupled, step, ema_decay, n, stream);
+}
+
+// two optimiser steps (`step`, `step + 1`) on the same clipped gradients in one pass, the EMA updated between them:
+// bit-identical to sedd_adamw_ema_step(step, ema_decay) followed by sedd_adamw_ema_step(step + 1, ema_decay = 1)
+extern "C" int sedd_adamw_ema_double_step(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                                          const float* clip_coef, float grad_scale, float lr, float beta1, float beta2,
+                                          float eps, float weight_decay, int decoupled, int step, float ema_decay,
+                                          int64_t n, sedd_stream_t stream) {
+    return adamw_ema_launch(2, p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay,
+                            decoupled, step, ema_decay, n, stream);
 }
 
 __global__ void __launch_bounds__(TPB) ema_update_kernel(float* __restrict__ s, const float* __restrict__ p, float omd,

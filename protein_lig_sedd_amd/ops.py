@@ -828,6 +828,15 @@ def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, be
           "sedd_adamw_ema_step")
 
 
+def adamw_ema_double_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
+                          ema_decay, decoupled=True):
+    """steps `step` and `step + 1` on the same gradients, EMA between them (the dual-track trainer's quirk Q2), one pass."""
+    check(lib().sedd_adamw_ema_double_step(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(p_bf16), _p(clip_coef),
+                                           float(grad_scale), float(lr), float(beta1), float(beta2), float(eps),
+                                           float(weight_decay), 1 if decoupled else 0, int(step), float(ema_decay),
+                                           p.numel(), _stream()), "sedd_adamw_ema_double_step")
+
+
 def ema_update_(shadow, p, one_minus_decay):
     check(lib().sedd_ema_update(_p(shadow), _p(p), float(one_minus_decay), shadow.numel(), _stream()), "sedd_ema_update")
     return shadow

@@ -481,12 +481,13 @@ class CrossAttTrainer(SEDDTrainer):
         self.ema.num_updates += 1
         decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
         self.opt_steps += 1
-        ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
-                           self.wd, self.opt_steps, decay, self.decoupled_wd)
-        if self.double_step:  # Q2: the same clipped gradients once more; EMA already took the first step's weights
+        if self.double_step:  # Q2: the same clipped gradients twice; the EMA takes the first step's weights (one pass)
+            ops.adamw_ema_double_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
+                                      self.eps, self.wd, self.opt_steps, decay, self.decoupled_wd)
             self.opt_steps += 1
-            ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
-                               self.eps, self.wd, self.opt_steps, 1.0, self.decoupled_wd)
+        else:
+            ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
+                               self.wd, self.opt_steps, decay, self.decoupled_wd)
         fl.refresh_compute_weights()
         if task == "joint":
             return loss.detach(), out[1].mean().detach(), out[2].mean().detach()

@@ -235,6 +235,28 @@ def test_adam_l2_and_zero_clip_match_torch():
     assert float(out[1]) == 7.0 and abs(float(out[0]) - float((g.double() ** 2).sum())) < 1e-3 * n
 
 
+def test_adamw_double_step_equals_two_single_steps():
+    """sedd_adamw_ema_double_step (quirk Q2 of the dual-track trainer in one pass) is bit-identical to two single steps on
+    the same gradients with the EMA update between them — weights, moments, EMA shadow and the bf16 compute copy."""
+    from protein_lig_sedd_amd import ops
+    torch.manual_seed(3)
+    n = 1 << 20
+    for decoupled in (True, False):
+        p = torch.randn(n, device=DEV)
+        g, m, v = torch.randn(n, device=DEV), 0.1 * torch.randn(n, device=DEV), 0.01 * torch.rand(n, device=DEV)
+        ema, clip = torch.randn(n, device=DEV), torch.tensor([0.7], device=DEV)
+        a = [t.clone() for t in (p, m, v, ema)] + [torch.zeros(n, dtype=torch.bfloat16, device=DEV)]
+        b = [t.clone() for t in (p, m, v, ema)] + [torch.zeros(n, dtype=torch.bfloat16, device=DEV)]
+        for first in (1, 3):
+            args = (clip, 0.5, 3e-3, 0.9, 0.999, 1e-8, 0.01)
+            ops.adamw_ema_step(a[0], g, a[1], a[2], a[3], a[4], *args, first, 0.99, decoupled)
+            ops.adamw_ema_step(a[0], g, a[1], a[2], a[3], a[4], *args, first + 1, 1.0, decoupled)
+            ops.adamw_ema_double_step(b[0], g, b[1], b[2], b[3], b[4], *args, first, 0.99, decoupled)
+            for x, y, name in zip(a, b, ("p", "m", "v", "ema", "p_bf16")):
+                assert torch.equal(x, y), (name, decoupled, first)
+        assert not torch.equal(a[0], p)
+
+
 def test_train_step_is_bit_reproducible():
     """Two trainers built from the same seed take the same steps (same data, noise and dropout seeds): every gradient and
     every parameter must agree bit for bit — all reductions of the SEDD train step fold in a fixed order (split-K slabs,
