@@ -237,7 +237,8 @@ int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
                  int64_t K, sedd_stream_t stream);
 /* sedd_gemm_nt with a caller-owned workspace (16-byte aligned, may be NULL): accumulating fp32 outputs of small shapes
  * (one or a few output tiles, a long reduction: the adaLN conditioning gradient, the [V, D] output-layer weight
- * gradient) split K over blocks; with workspace_bytes >= 4 * slices * M * N (slices <= 64) the slices park their partial
+ * gradient; fp32 operands: any output of fewer than 128 tiles of 64 x 64, accumulating or not, bias allowed) split K
+ * over blocks; with workspace_bytes >= 4 * slices * M * N (slices <= 64) the slices park their partial
  * tiles there and a fixed-order fold adds them to C — bit-reproducible run to run — instead of adding to C with fp32
  * atomics.  Everything else as sedd_gemm_nt. */
 int sedd_gemm_nt_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
@@ -270,6 +271,13 @@ int sedd_gemm_nt_rotary(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * of 4; 16-byte aligned bases; otherwise SEDD_ERR_UNSUPPORTED_SHAPE (callers then transpose + sedd_gemm_nt). */
 int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K, sedd_stream_t stream);
+/* sedd_gemm_nn with a caller-owned workspace (16-byte aligned, may be NULL), as sedd_gemm_nt_ws: an fp32 product whose
+ * output has fewer than 128 tiles of 64 x 64 (the ligand track's data gradients: a few hundred rows against a long
+ * reduction) splits K over blocks when workspace_bytes >= 4 * slices * M * N (slices <= 4), and a fixed-order fold adds
+ * the slices (and the bias) — bit-reproducible.  bf16 products ignore the workspace. */
+int sedd_gemm_nn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                    int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K, void* workspace,
+                    int64_t workspace_bytes, sedd_stream_t stream);
 /* sedd_gemm_nt_dgelu with B given as [K, N] (the second MLP weight as stored, transformer.py:132):
  * C = (A[M,K] * B[K,N]) .* gelu_tanh'(pre[M,N]); colsum += column sums of C.  Same requirements as sedd_gemm_nn. */
 int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,

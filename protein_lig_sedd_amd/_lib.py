@@ -57,6 +57,7 @@ SIGNATURES = {
     "sedd_gemm_tn": "plplpliiilllplp",
     "sedd_gemm_nt_dgelu": "plplpliippplllp",
     "sedd_gemm_nn": "plplpliipilllp",
+    "sedd_gemm_nn_ws": "plplpliipilllplp",
     "sedd_gemm_nt_rotary": "plplpliipippiiilllp",
     "sedd_gemm_nn_dgelu": "plplpliippplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",

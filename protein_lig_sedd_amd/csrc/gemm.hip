@@ -280,11 +280,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_nt_glds_kernel(const bf16_t* __
 // C[m][n] += slab[0][m][n] + slab[1][m][n] + ... (slice order): the deterministic form of the split-K above
 __global__ void __launch_bounds__(256) splitk_fold_kernel(const float* __restrict__ slabs, int nslices, int64_t M,
                                                           int64_t N, float* __restrict__ C, int64_t ldc,
-                                                          int accumulate = 1) {
+                                                          int accumulate = 1, const float* __restrict__ bias = nullptr) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= M * N) return;
     float s = 0.f;
     for (int k = 0; k < nslices; ++k) s += slabs[(int64_t)k * M * N + e];
+    if (bias) s += bias[e % N];
     float* c = C + (e / N) * ldc + e % N;
     *c = accumulate ? *c + s : s;
 }
@@ -1183,7 +1184,8 @@ __global__ void __launch_bounds__(256) colsum_fold_kernel(const float* __restric
 }
 
 // fp32 products.  layout 0: A [M,K], B [N,K] (NT)   1: A [M,K], B [K,N] (NN)   2: A [K,M], B [K,N] (TN).
-// ws (optional, fp32 output without epilogue only): scratch for splitting K when even 64 x 64 tiles leave CUs idle.
+// ws (optional; fp32 output, no epilogue or bias only): scratch for splitting K when even 64 x 64 tiles leave CUs idle
+// (the fold adds the bias).
 static int gemm_f32_launch(int layout, const float* A, int64_t lda, const float* B, int64_t ldb, void* C, int64_t ldc,
                            int out_dtype, const float* bias, int epi, void* pre, int accumulate, int64_t M, int64_t N,
                            int64_t K, float* ws, int64_t ws_bytes, hipStream_t st) {
@@ -1210,7 +1212,7 @@ static int gemm_f32_launch(int layout, const float* A, int64_t lda, const float*
     // K step: 64 for the 64 x 64 tile (16 MFMAs per wave and step would not cover a global-load latency), else 32
     const int bk = best == 2 ? 64 : 32;
     int64_t kper = (K + bk - 1) / bk * bk;
-    if (best == 2 && ws && out_dtype == SEDD_F32 && epi == SEDD_EPI_NONE) {
+    if (best == 2 && ws && out_dtype == SEDD_F32 && (epi == SEDD_EPI_NONE || epi == SEDD_EPI_BIAS)) {
         // every slice keeps >= 256 of K; slices x tiles stay within two blocks per CU
         while (best_tiles * splitk * 2 <= 512 && kper % (2 * bk) == 0 && kper / 2 >= 256 &&
                (int64_t)splitk * 2 * M * N * 4 <= ws_bytes)
@@ -1235,7 +1237,7 @@ static int gemm_f32_launch(int layout, const float* A, int64_t lda, const float*
     SEDD_LAUNCH_CHECK();
     if (slabs) {
         hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, slabs, splitk, M,
-                           N, (float*)C, ldc, accumulate);
+                           N, (float*)C, ldc, accumulate, epi == SEDD_EPI_BIAS ? bias : (const float*)nullptr);
         SEDD_LAUNCH_CHECK();
     }
     return SEDD_OK;
@@ -1450,9 +1452,9 @@ extern "C" int sedd_gemm_nt_rotary(const void* A, int64_t lda, const void* B, in
 
 // C[M,N] = A[M,K] * B[K,N] (bf16): the data gradient of nn.Linear against the weight as stored (dX = dY W, W [out, in]),
 // no transposed weight copy.  epilogue: SEDD_EPI_NONE or SEDD_EPI_BIAS.
-extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
-                            int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K,
-                            sedd_stream_t stream) {
+static int gemm_nn_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                        int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K, void* workspace,
+                        int64_t workspace_bytes, sedd_stream_t stream) {
     SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == SEDD_EPI_BIAS, "gemm_nn: bad epilogue %d", epilogue);
     if (in_dtype == SEDD_F32) {  // exact-fp32 MFMA kernel reading B as stored
         SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_nn: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
@@ -1466,11 +1468,29 @@ extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t l
         }
         if (M == 0 || N == 0) return SEDD_OK;
         SEDD_CHECK_ARG(A && B && C, "gemm_nn: null pointer");
+        const bool ws_ok = workspace && ((uintptr_t)workspace & 15) == 0;
         return gemm_f32_launch(1, (const float*)A, lda, (const float*)B, ldb, C, ldc, out_dtype, bias, epilogue, nullptr,
-                               0, M, N, K, nullptr, 0, (hipStream_t)stream);
+                               0, M, N, K, ws_ok ? (float*)workspace : nullptr, ws_ok ? workspace_bytes : 0,
+                               (hipStream_t)stream);
     }
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, nullptr, 0, M, N, K, nullptr, stream,
                         true);
+}
+
+extern "C" int sedd_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                            int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K,
+                            sedd_stream_t stream) {
+    return gemm_nn_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, M, N, K, nullptr, 0, stream);
+}
+
+// sedd_gemm_nn with a caller-owned workspace: fp32 products whose output has fewer than 128 tiles of 64 x 64 split K over
+// blocks and fold the slices in a fixed order (bf16 products ignore it)
+extern "C" int sedd_gemm_nn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                               int out_dtype, const float* bias, int epilogue, int64_t M, int64_t N, int64_t K,
+                               void* workspace, int64_t workspace_bytes, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(workspace_bytes >= 0, "gemm_nn_ws: bad workspace");
+    return gemm_nn_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, M, N, K, workspace, workspace_bytes,
+                        stream);
 }
 
 // sedd_gemm_nt_dgelu with B given as [K, N]: dU = (dY W2) .* gelu'(U), colsum += column sums, W2 [out, hidden] as stored

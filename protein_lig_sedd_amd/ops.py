@@ -540,13 +540,13 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
-        if accumulate and out.dtype == torch.float32 and not _ATOMIC:
+        if out.dtype == torch.float32 and not _ATOMIC and (accumulate or A.dtype == torch.float32):
             # launches that split K (small outputs, long reductions) fold their slices in a fixed order out of the
             # split-K scratch instead of adding to `out` with atomics
             ws = _tn_workspace(A.device)
             check(lib().sedd_gemm_nt_ws(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                                        _p(bias), epi, _p(pre), 1, M, N, K, _p(ws), ws.numel() * 4, _stream()),
-                  "sedd_gemm_nt_ws")
+                                        _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _p(ws), ws.numel() * 4,
+                                        _stream()), "sedd_gemm_nt_ws")
         else:
             check(lib().sedd_gemm_nt(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                      _p(bias), epi, _p(pre), 1 if accumulate else 0, M, N, K, _stream()), "sedd_gemm_nt")
@@ -645,8 +645,13 @@ def gemm_nn(A, B, bias=None, out=None):
         out = torch.empty(M, N, dtype=A.dtype, device=A.device)
     epi = _L.EPI_NONE if bias is None else _L.EPI_BIAS
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
-        check(lib().sedd_gemm_nn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
-                                 _p(bias), epi, M, N, K, _stream()), "sedd_gemm_nn")
+        if A.dtype == torch.float32 and not _ATOMIC:  # small fp32 outputs split K through the scratch
+            ws = _tn_workspace(A.device)
+            check(lib().sedd_gemm_nn_ws(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                        _p(bias), epi, M, N, K, _p(ws), ws.numel() * 4, _stream()), "sedd_gemm_nn_ws")
+        else:
+            check(lib().sedd_gemm_nn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
+                                     _p(bias), epi, M, N, K, _stream()), "sedd_gemm_nn")
     return out
 
 

@@ -19,7 +19,7 @@ def _ops():
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (8, 4608, 128), (1024, 26, 768), (64, 64, 8),
-                                   (257, 129, 776)])
+                                   (257, 129, 776), (512, 1024, 2048), (2048, 1024, 1024), (1, 4, 4)])
 def test_gemm_fp32(M, N, K):
     ops = _ops()
     torch.manual_seed(M + N + K)
@@ -35,6 +35,41 @@ def test_gemm_fp32(M, N, K):
     C0 = C.clone()
     ops.gemm_nt(A, B, out=C, accumulate=True)
     assert rel_err(C, C0.double() + ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (8, 4608, 128), (64, 64, 8), (512, 1024, 2048),
+                                   (2048, 1024, 1024), (300, 136, 96), (1, 4, 4), (1028, 260, 72)])
+def test_gemm_nn_tn_fp32(M, N, K):
+    """the exact-fp32 kernel's other two operand layouts — B stored [K, N] (data gradient), A stored [K, M] and B [K, N]
+    (weight gradient, any K) — against float64, incl. strided operands, bias, accumulation and the split-K shapes."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    A, B = torch.randn(M, K, device=DEV), torch.randn(K, N, device=DEV)
+    bias = torch.randn(N, device=DEV)
+    ref = A.double() @ B.double()
+    assert ops.gemm_nn_supported(A, B)
+    assert rel_err(ops.gemm_nn(A, B), ref) < 2e-6
+    assert rel_err(ops.gemm_nn(A, B, bias=bias), ref + bias.double()) < 2e-6
+    Aw = torch.randn(M, K + 8, device=DEV)
+    Bw = torch.randn(K, N + 8, device=DEV)
+    out = torch.full((M, N + 4), 7.0, device=DEV)
+    ops.gemm_nn(Aw[:, 4:4 + K], Bw[:, 4:4 + N], out=out[:, :N])
+    assert rel_err(out[:, :N], Aw[:, 4:4 + K].double() @ Bw[:, 4:4 + N].double()) < 2e-6
+    assert bool((out[:, N:] == 7.0).all())
+    if M % 4 == 0:
+        At = A.t().contiguous()  # [K, M]
+        assert ops.gemm_tn_supported(At, B)
+        assert rel_err(ops.gemm_tn(At, B), ref) < 2e-6
+        C = torch.randn(M, N, device=DEV)
+        C0 = C.clone()
+        ops.gemm_tn(At, B, out=C, accumulate=True)
+        assert rel_err(C, C0.double() + ref) < 2e-6
+        ops.gemm_tn(At, B, out=C, accumulate=False)
+        assert rel_err(C, ref) < 2e-6
+        odd = At[:K - 1] if K > 1 else At  # a reduction length that is a multiple of nothing
+        assert rel_err(ops.gemm_tn(odd, B[:odd.shape[0]]), odd.double().T @ B[:odd.shape[0]].double()) < 2e-6
+    assert not ops.gemm_nn_supported(A, torch.randn(K, N + 1, device=DEV)[:, :N + 1])
+    assert not ops.gemm_tn_supported(torch.randn(K, M + 2, device=DEV), B)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (64, 4608, 128), (2048, 26, 768), (512, 768, 3072),
