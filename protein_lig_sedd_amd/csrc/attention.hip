@@ -734,6 +734,171 @@ attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* _
         }
 }
 
+// ============================================================================================ tiny sequences
+// The dual-track model's self-attention as written (quirk Q1: nn.MultiheadAttention batch_first applied to [L, B, D], so
+// the "sequence" is the batch index) attends over B = 4 keys in L * H = 16384 independent problems: a 128-query x
+// 64-key tile per (batch, head) block is almost all padding there.  For Lq, Lk <= SMALL_L and d = 32 one THREAD owns one
+// (batch, head, row): the row stays in registers, the other side's <= 16 rows stream through as 128-byte loads (adjacent
+// threads = adjacent heads, then adjacent batches: consecutive addresses), all arithmetic fp32 on the vector ALU in the
+// tile kernels' formulas (exp2 against the row maximum, LSE = (m + log2 l) ln 2, the scale applied once to dQ / dK).
+constexpr int SMALL_L = 16;
+template <typename T> __device__ __forceinline__ void small_load32(const T* p, float* r);
+template <> __device__ __forceinline__ void small_load32<float>(const float* p, float* r) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 x = reinterpret_cast<const float4*>(p)[c];
+        r[4 * c] = x.x; r[4 * c + 1] = x.y; r[4 * c + 2] = x.z; r[4 * c + 3] = x.w;
+    }
+}
+template <> __device__ __forceinline__ void small_load32<bf16_t>(const bf16_t* p, float* r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bf16x8 x = reinterpret_cast<const bf16x8*>(p)[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[8 * c + e] = (float)x[e];
+    }
+}
+template <typename T> __device__ __forceinline__ void small_store32(T* p, const float* r, float mul);
+template <> __device__ __forceinline__ void small_store32<float>(float* p, const float* r, float mul) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        reinterpret_cast<float4*>(p)[c] = make_float4(r[4 * c] * mul, r[4 * c + 1] * mul, r[4 * c + 2] * mul, r[4 * c + 3] * mul);
+}
+template <> __device__ __forceinline__ void small_store32<bf16_t>(bf16_t* p, const float* r, float mul) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bf16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (bf16_t)(r[8 * c + e] * mul);
+        reinterpret_cast<bf16x8*>(p)[c] = x;
+    }
+}
+__device__ __forceinline__ float small_dot32(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) s = fmaf(a[e], b[e], s);
+    return s;
+}
+// thread -> (row, batch, head), heads fastest
+#define SMALL_INDEX(L_)                                                         \
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;                 \
+    if (idx >= (int64_t)B * sh.H * (L_)) return;                                 \
+    const int h = (int)(idx % sh.H), b = (int)((idx / sh.H) % B), row = (int)(idx / ((int64_t)sh.H * B));
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_small_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                             const T* __restrict__ v, T* __restrict__ o,
+                                                             float* __restrict__ lse, const uint8_t* __restrict__ mask,
+                                                             AttnShape sh, int B) {
+    SMALL_INDEX(sh.Lq)
+    const float sl2 = sh.scale * LOG2E;
+    float qr[32], s[SMALL_L];
+    small_load32<T>(q + b * sh.q_bs + row * sh.q_ls + h * 32, qr);
+    const T* kb = k + b * sh.kv_bs + h * 32;
+    const T* vb = v + b * sh.kv_bs + h * 32;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SMALL_L; ++j) {
+        s[j] = -INFINITY;
+        if (j < sh.Lk && (!mask || mask[(int64_t)b * sh.Lk + j])) {
+            float kr[32];
+            small_load32<T>(kb + j * sh.kv_ls, kr);
+            s[j] = small_dot32(qr, kr);
+            mx = fmaxf(mx, s[j]);
+        }
+    }
+    const float m2 = mx * sl2, ms = mx == -INFINITY ? 0.f : m2;
+    float l = 0.f, acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMALL_L; ++j) {
+        if (j < sh.Lk) {
+            const float p = fast_exp2(fmaf(s[j], sl2, -ms));  // (masked: exp2(-inf) = 0)
+            l += p;
+            float vr[32];
+            small_load32<T>(vb + j * sh.kv_ls, vr);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc[e] = fmaf(p, vr[e], acc[e]);
+        }
+    }
+    small_store32<T>(o + b * sh.o_bs + row * sh.o_ls + h * 32, acc, l > 0.f ? 1.0f / l : 0.f);
+    lse[((int64_t)b * sh.H + h) * sh.Lq + row] = (m2 + log2f(l)) * LN2;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_small_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                            const T* __restrict__ v, const T* __restrict__ o,
+                                                            const T* __restrict__ dout, const float* __restrict__ lse,
+                                                            float* __restrict__ delta, const uint8_t* __restrict__ mask,
+                                                            T* __restrict__ dq, AttnShape sh, int B) {
+    SMALL_INDEX(sh.Lq)
+    const float sl2 = sh.scale * LOG2E;
+    float qr[32], dor[32], acc[32];
+    small_load32<T>(q + b * sh.q_bs + row * sh.q_ls + h * 32, qr);
+    small_load32<T>(dout + b * sh.o_bs + row * sh.o_ls + h * 32, dor);
+    small_load32<T>(o + b * sh.o_bs + row * sh.o_ls + h * 32, acc);
+    const float dl = small_dot32(acc, dor);
+    const int64_t li = ((int64_t)b * sh.H + h) * sh.Lq + row;
+    delta[li] = dl;
+    const float l2 = lse[li] * LOG2E;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc[e] = 0.f;
+    const T* kb = k + b * sh.kv_bs + h * 32;
+    const T* vb = v + b * sh.kv_bs + h * 32;
+    for (int j = 0; j < sh.Lk; ++j) {
+        if (mask && !mask[(int64_t)b * sh.Lk + j]) continue;
+        float kr[32], vr[32];
+        small_load32<T>(kb + j * sh.kv_ls, kr);
+        small_load32<T>(vb + j * sh.kv_ls, vr);
+        const float p = fast_exp2(fmaf(small_dot32(qr, kr), sl2, -l2));
+        const float ds = p * (small_dot32(dor, vr) - dl);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) acc[e] = fmaf(ds, kr[e], acc[e]);
+    }
+    small_store32<T>(dq + b * sh.q_bs + row * sh.q_ls + h * 32, acc, sh.scale);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_small_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                             const T* __restrict__ v, const T* __restrict__ dout,
+                                                             const float* __restrict__ lse,
+                                                             const float* __restrict__ delta,
+                                                             const uint8_t* __restrict__ mask, T* __restrict__ dk,
+                                                             T* __restrict__ dv, AttnShape sh, int B) {
+    SMALL_INDEX(sh.Lk)
+    const float sl2 = sh.scale * LOG2E;
+    float kr[32], vr[32], ak[32], av[32];
+    small_load32<T>(k + b * sh.kv_bs + row * sh.kv_ls + h * 32, kr);
+    small_load32<T>(v + b * sh.kv_bs + row * sh.kv_ls + h * 32, vr);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ak[e] = av[e] = 0.f;
+    if (!mask || mask[(int64_t)b * sh.Lk + row]) {
+        const T* qb = q + b * sh.q_bs + h * 32;
+        const T* db = dout + b * sh.o_bs + h * 32;
+        for (int i = 0; i < sh.Lq; ++i) {
+            float qr[32], dor[32];
+            small_load32<T>(qb + i * sh.q_ls, qr);
+            small_load32<T>(db + i * sh.o_ls, dor);
+            const int64_t li = ((int64_t)b * sh.H + h) * sh.Lq + i;
+            const float p = fast_exp2(fmaf(small_dot32(qr, kr), sl2, -lse[li] * LOG2E));
+            const float ds = p * (small_dot32(dor, vr) - delta[li]);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                av[e] = fmaf(p, dor[e], av[e]);
+                ak[e] = fmaf(ds, qr[e], ak[e]);
+            }
+        }
+    }
+    small_store32<T>(dk + b * sh.kv_bs + row * sh.kv_ls + h * 32, ak, sh.scale);
+    small_store32<T>(dv + b * sh.kv_bs + row * sh.kv_ls + h * 32, av, 1.0f);
+}
+#undef SMALL_INDEX
+static bool attn_small_ok(int Lq, int Lk, int d, const int* cu) {
+    static const bool off = getenv("SEDD_NO_SMALL_ATTN") != nullptr;  // A/B knob
+    return !off && !cu && d == 32 && Lq <= SMALL_L && Lk <= SMALL_L;
+}
+
 // ==================================================================================================== host
 static int check_attn(const char* nm, int dtype, int B, int H, int Lq, int Lk, int d, int64_t q_bs, int64_t q_ls,
                       int64_t kv_bs, int64_t kv_ls, int64_t o_bs, int64_t o_ls) {
@@ -774,6 +939,17 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr, cu, total};
+    if (attn_small_ok(Lq, Lk, d, cu)) {
+        const dim3 gs((unsigned)(((int64_t)B * H * Lq + 255) / 256));
+        if (dtype == SEDD_BF16)
+            hipLaunchKernelGGL(attn_small_fwd_kernel<bf16_t>, gs, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, key_mask, sh, B);
+        else
+            hipLaunchKernelGGL(attn_small_fwd_kernel<float>, gs, dim3(256), 0, (hipStream_t)stream, (const float*)q,
+                               (const float*)k, (const float*)v, (float*)o, lse, key_mask, sh, B);
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     const dim3 grid((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
     const bool plain = !key_mask && !cu && Lk % TILE == 0;  // (bf16 only: the fp32 instantiations are the parity path)
 #define FWD_LAUNCH(PL) hipLaunchKernelGGL((attn_fwd_kernel<T, D, PL>), grid, dim3(256), 0, (hipStream_t)stream,       \
@@ -802,6 +978,18 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin, cu, total};
     hipStream_t st = (hipStream_t)stream;
+    if (attn_small_ok(Lq, Lk, d, cu) && !rot_cos) {
+        const dim3 gsq((unsigned)(((int64_t)B * H * Lq + 255) / 256)), gsk((unsigned)(((int64_t)B * H * Lk + 255) / 256));
+#define SMALL_BWD(T)                                                                                                   \
+        hipLaunchKernelGGL(attn_small_dq_kernel<T>, gsq, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,      \
+                           (const T*)o, (const T*)dout, lse, delta, key_mask, (T*)dq, sh, B);                          \
+        hipLaunchKernelGGL(attn_small_dkv_kernel<T>, gsk, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,     \
+                           (const T*)dout, lse, delta, key_mask, (T*)dk, (T*)dv, sh, B)
+        if (dtype == SEDD_BF16) { SMALL_BWD(bf16_t); } else { SMALL_BWD(float); }
+#undef SMALL_BWD
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     const dim3 gq((unsigned)((int64_t)((Lq + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H)),
         gk((unsigned)((int64_t)((Lk + OWN_PER_BLOCK - 1) / OWN_PER_BLOCK) * B * H));
     const bool plain_q = !key_mask && !cu && Lk % TILE == 0, plain_k = !key_mask && !cu && Lk % OWN_PER_BLOCK == 0;

@@ -453,7 +453,8 @@ def _ref_attn(q, k, v, mask):
 
 @pytest.mark.parametrize("d", [32, 64, 96])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Lq,Lk,masked", [(128, 128, False), (70, 70, False), (100, 45, True), (4, 4, False), (200, 130, True)])
+@pytest.mark.parametrize("Lq,Lk,masked", [(128, 128, False), (70, 70, False), (100, 45, True), (4, 4, False), (200, 130, True),
+                                          (16, 9, True), (3, 16, True), (1, 2, False), (17, 16, False)])
 def test_attention(d, dtype, Lq, Lk, masked):
     ops = _ops()
     torch.manual_seed(d + Lq)
@@ -490,6 +491,33 @@ def test_attention(d, dtype, Lq, Lk, masked):
     assert rel_err(dq, qr.grad) < tolb, "dq"
     assert rel_err(dk, kr.grad) < tolb, "dk"
     assert rel_err(dv, vr.grad) < tolb, "dv"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_over_the_batch_axis(dtype):
+    """the dual-track model's self-attention as written (quirk Q1, transformers_protlig_cross.py:305: batch_first MHA on
+    [L, B, D]): 'sequence' = the batch index (4 here), 'batch' = the positions — transposed strided views, many tiny
+    problems (the one-thread-per-row kernels for d = 32), outputs written through the same transposed views."""
+    ops = _ops()
+    torch.manual_seed(5)
+    Bt, L, H, d = 4, 37, 5, 32
+    q, k, v, dout = (torch.randn(Bt, L, H, d) for _ in range(4))
+    if dtype == torch.bfloat16:
+        q, k, v, dout = (t.bfloat16().float() for t in (q, k, v, dout))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _ref_attn(qr.transpose(0, 1), kr.transpose(0, 1), vr.transpose(0, 1), None)  # [L, Bt, H, d]: attends over Bt
+    ref.backward(dout.transpose(0, 1))
+    qd, kd, vd, dd = (t.to(DEV).to(dtype) for t in (q, k, v, dout))
+    o = torch.empty_like(qd)
+    _, lse = ops.attn_fwd(qd.transpose(0, 1), kd.transpose(0, 1), vd.transpose(0, 1), out=o.transpose(0, 1))
+    tol, tolb = (2e-5, 5e-5) if dtype == torch.float32 else (1e-2, 2e-2)
+    assert rel_err(o.transpose(0, 1), ref) < tol
+    s = torch.einsum("blhd,bmhd->bhlm", q.transpose(0, 1), k.transpose(0, 1)) * d ** -0.5
+    assert_close(lse, torch.logsumexp(s, -1), 2e-3, 2e-3, "lse")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attn_bwd(qd.transpose(0, 1), kd.transpose(0, 1), vd.transpose(0, 1), o.transpose(0, 1), dd.transpose(0, 1), lse,
+                 dq.transpose(0, 1), dk.transpose(0, 1), dv.transpose(0, 1))
+    assert rel_err(dq, qr.grad) < tolb and rel_err(dk, kr.grad) < tolb and rel_err(dv, vr.grad) < tolb
 
 
 def test_attention_packed_qkv_and_spike():
