@@ -1186,12 +1186,55 @@ __global__ void __launch_bounds__(TPB) colsum_rows_fold_kernel(const float* __re
     for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0 && c < N) out[c] += s;
 }
+// a few thousand rows (the dual-track model's batch of 4): ONE launch — no scratch, no fold launch, no memset.  The sum
+// is latency-bound (megabytes, read once, cold): a block takes 8 columns x 32 row groups and every thread keeps 16
+// independent loads in flight, so 2048 rows are 4 round trips to memory; the 32 partials of a column are combined
+// through LDS in a fixed order.
+#define CS_TALL_MAX 8192
+template <typename T>
+__global__ void __launch_bounds__(TPB) colsum_tall_kernel(const T* __restrict__ a, int64_t lda, float* __restrict__ out,
+                                                          int64_t M, int N, int accumulate) {
+    static_assert(TPB == 256, "32 row groups x 8 columns");
+    __shared__ float red[32][8];
+    const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
+    float s[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] = 0.f;
+    if (c < N) {
+        const T* p = a + c;
+        int64_t r = rg;
+        for (; r + 15 * 32 < M; r += 16 * 32) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s[u] += to_f32<T>(p[(r + u * 32) * lda]);
+        }
+        for (; r < M; r += 32) s[0] += to_f32<T>(p[r * lda]);
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) s[u] += s[u + w];
+    red[rg][cl] = s[0];
+    __syncthreads();
+    if (rg == 0 && c < N) {
+        float t = red[0][cl];
+#pragma unroll
+        for (int g = 1; g < 32; ++g) t += red[g][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
 extern "C" int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, float* ws, int accumulate, int64_t M, int N,
                            sedd_stream_t stream) {
     SEDD_CHECK_ARG(dt_ok(dtype), "colsum: bad dtype");
     SEDD_CHECK_ARG(M >= 0 && N > 0 && lda >= N, "colsum: bad sizes");
     SEDD_CHECK_ARG(out, "colsum: out is null");
     hipStream_t st = (hipStream_t)stream;
+    if (M > 0 && M <= CS_TALL_MAX && N >= 256) {
+        SEDD_CHECK_ARG(a, "colsum: a is null");
+        DISPATCH_DT(dtype, T, hipLaunchKernelGGL((colsum_tall_kernel<T>), dim3((N + 7) / 8), dim3(TPB), 0, st, (const T*)a,
+                                                 lda, out, M, N, accumulate));
+        SEDD_LAUNCH_CHECK();
+        return SEDD_OK;
+    }
     if (!accumulate) {
         if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { sedd_set_error("colsum: memset failed"); return SEDD_ERR_LAUNCH; }
     }

@@ -65,9 +65,12 @@ class FlatState:
 
     def refresh_compute_weights(self):
         """(re)attach the compute-dtype copies after the flat buffers changed behind autograd's back."""
-        for i, p in enumerate(self.params):
-            if p.dim() == 2:
-                Lyr.set_compute_weight(p, self.compute_dtype, p.detach() if self.pc is None else self.view(self.pc, i))
+        views = getattr(self, "_cw_views", None)
+        if views is None:  # the views never change, only the parameter versions they are tagged with
+            views = self._cw_views = [(p, p.detach() if self.pc is None else self.view(self.pc, i))
+                                      for i, p in enumerate(self.params) if p.dim() == 2]
+        for p, v in views:
+            Lyr.set_compute_weight(p, self.compute_dtype, v)
 
     def ema_params(self):
         return [self.view(self.ema, i) for i in range(len(self.params))]
@@ -198,7 +201,8 @@ class SEDDTrainer:
         """One optimisation step (losses.py:80-115 with accum = 1). Returns the local loss (0-dim device tensor)."""
         fl = self.flat
         fl.g.zero_()
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
         loss.backward()
         self.apply_gradients()
@@ -467,7 +471,8 @@ class CrossAttTrainer(SEDDTrainer):
         task = task or self.task
         fl = self.flat
         fl.g.zero_()
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         out = self.calc_loss(batch, task, t=t, perturbed=perturbed)
         loss = out[0].mean() if task == "joint" else out.mean()
         loss.backward()

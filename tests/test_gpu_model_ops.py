@@ -411,6 +411,15 @@ def test_gelu_silu_embed_epilogue_colsum_transpose():
     a = torch.randn(777, 130, device=DEV)
     assert rel_err(ops.colsum(a), a.sum(0)) < 1e-5
     assert rel_err(ops.colsum(a.bfloat16()), a.bfloat16().float().sum(0)) < 1e-5
+    for Mc, Nc in ((2048, 1024), (515, 300), (8192, 256), (7, 4096)):  # the one-launch form for a few thousand rows
+        for dt in (torch.float32, torch.bfloat16):
+            t = torch.randn(Mc, Nc + 8, device=DEV).to(dt)[:, 4:4 + Nc]  # (strided rows)
+            got = ops.colsum(t)
+            assert rel_err(got, t.double().sum(0)) < 1e-5
+            assert torch.equal(got, ops.colsum(t)), "fixed summation order"
+            acc2 = torch.full((Nc,), 2.0, device=DEV)
+            ops.colsum(t, out=acc2, accumulate=True)
+            assert rel_err(acc2, 2.0 + t.double().sum(0)) < 1e-5
     acc = torch.ones(130, device=DEV)
     ops.colsum(a, out=acc, accumulate=True)
     assert rel_err(acc, a.sum(0) + 1) < 1e-5

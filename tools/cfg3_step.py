@@ -28,9 +28,10 @@ for name in os.environ.get("CFG3_DTYPES", "fp32,bf16").split(","):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n): out = tr.train_step(bs[i % 4])
+    host = (time.perf_counter() - t0) / n  # time to ENQUEUE a step: ~ the step time when the host is the limiter
     torch.cuda.synchronize()
     s = (time.perf_counter() - t0) / n
     P = sum(p.numel() for p in model.parameters())
-    print(f"cfg3 {name} batch {B}: {s*1e3:.2f} ms/step, {B*(Lp+Ll)/s:.0f} tokens/s ({B/s:.1f} pairs/s), params {P/1e6:.1f} M, loss {float(out[0]):.4f}", flush=True)
+    print(f"cfg3 {name} batch {B}: {s*1e3:.2f} ms/step, {B*(Lp+Ll)/s:.0f} tokens/s ({B/s:.1f} pairs/s), params {P/1e6:.1f} M, loss {float(out[0]):.4f}, host enqueue {host*1e3:.2f} ms/step", flush=True)
     del tr, model
     torch.cuda.empty_cache()
