@@ -17,6 +17,7 @@ import inspect
 import torch
 
 from . import _lib as _L
+from . import ops
 from .catsample import sample_categorical
 
 _PREDICTORS = {}
@@ -131,12 +132,46 @@ def get_sampling_fn(config, graph, noise, batch_dims, eps, device):
                           steps=config.sampling.steps, denoise=config.sampling.noise_removal, eps=eps, device=device)
 
 
+class _GraphedStep:
+    """One predictor update captured as a HIP graph: `x <- update(proj(x), t)` over static buffers, replayed once per
+    sampler step.  A small model's step is a few hundred launches of a few microseconds each and the Python between them
+    costs more than the kernels; the replay is one launch.  Everything that changes from step to step lives in device
+    memory (x, t, and the explicit noise when the caller passes one); the step size is the same Python float every step."""
+
+    def __init__(self, fn, x, t, u):
+        self.x, self.t = x.clone(), t.clone()
+        self.u = None if u is None else u.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):  # (lazy scratch allocations and the allocator's pools settle outside the capture)
+            for _ in range(2):
+                fn(self.x, self.t, self.u)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.x.copy_(fn(self.x, self.t, self.u))
+
+    def run(self, x, t_seq, noise_seq, steps):
+        self.x.copy_(x)
+        for i in range(steps):
+            self.t.copy_(t_seq[i])
+            if self.u is not None:
+                self.u.copy_(noise_seq[i])
+            self.graph.replay()
+        return self.x.clone()
+
+
 def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps=1e-5, device=torch.device('cpu'),
-                   proj_fun=lambda x: x):
-    """sampling.py:149-175"""
+                   proj_fun=lambda x: x, hip_graph=False):
+    """sampling.py:149-175.  hip_graph=True (not in the reference): the predictor update is captured once per (model,
+    task, conditioning, noise form) as a HIP graph and replayed `steps` times — same kernels, same tokens for the same
+    noise; for launch-bound (small) models.  It needs proj_fun and the model's forward to be capturable (device-side
+    work only) and takes noise_seq as explicit tensors or None (torch's generator), not as a PhiloxStream (whose offsets
+    are host integers)."""
     predictor = get_predictor(predictor)(graph, noise)
     projector = proj_fun
     denoiser = Denoiser(graph, noise)
+    graphed = {}
 
     @torch.no_grad()
     def pc_sampler(model, task=None, prot_indices=None, lig_indices=None, noise_seq=None, x_init=None):
@@ -148,8 +183,25 @@ def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps
         ones = torch.ones(x.shape[0], 1, device=device)
         mark = getattr(model, "sampling_step", None)  # dual-track model: per-step cache of the conditioning context
         mark = mark if callable(mark) else (lambda i: None)
+        use_graph = hip_graph and x.is_cuda and steps > 0
+        if use_graph and isinstance(noise_seq, ops.PhiloxStream):
+            raise ValueError("hip_graph=True takes noise_seq as tensors or None, not a PhiloxStream")
         try:
-            for i in range(steps):
+            if use_graph:
+                def one(xs, ts, us):
+                    return predictor.update_fn(score_model=model, x=projector(xs), t=ts, step_size=dt, task=task,
+                                               prot_indices=prot_indices, lig_indices=lig_indices, u=us)
+
+                u0 = None if noise_seq is None else noise_seq[0]
+                key = (id(model), task, None if prot_indices is None else prot_indices.data_ptr(),
+                       None if lig_indices is None else lig_indices.data_ptr(), tuple(x.shape),
+                       None if u0 is None else tuple(u0.shape))
+                if key not in graphed:
+                    mark(None)  # (the per-step context cache is host state: the captured step recomputes the context)
+                    graphed.clear()
+                    graphed[key] = _GraphedStep(one, x, timesteps[0] * ones, u0)
+                x = graphed[key].run(x, timesteps[:steps, None, None] * ones, noise_seq, steps)
+            for i in range(0 if use_graph else steps):
                 mark(i)
                 t = timesteps[i] * ones
                 x = projector(x)

@@ -192,9 +192,21 @@ def test_g13_pc_sampler_bit_exact(golden):
         seq = [u.to(DEV) for u in g[pred + "_u"]] + [g[pred + "_u_denoise"].to(DEV)]
         out = sampler(model, noise_seq=seq)
         assert int((out.cpu() != g[pred + "_out"]).sum()) == 0, pred
+        # the same run with the predictor update replayed as a HIP graph (twice: the second call reuses the capture)
+        gs = sampling.get_pc_sampler(graph, noise, (B, L), pred, steps, denoise=True, eps=1e-5, device=DEV, hip_graph=True)
+        for _ in range(2):
+            assert int((gs(model, noise_seq=seq).cpu() != g[pred + "_out"]).sum()) == 0, pred + " (graph)"
     # without supplied noise: valid ids, no mask left after the denoiser
     out = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, device=DEV)(model)
     assert int(((out < 0) | (out >= tokens)).sum()) == 0
+    # ... and under graph replay torch's generator advances per replay: valid ids, and two runs differ
+    gs = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, device=DEV, hip_graph=True)
+    o1, o2 = gs(model), gs(model)
+    assert int(((o1 < 0) | (o1 >= tokens)).sum()) == 0 and int(((o2 < 0) | (o2 >= tokens)).sum()) == 0
+    assert not torch.equal(o1, o2)
+    with pytest.raises(ValueError):
+        from protein_lig_sedd_amd import ops
+        gs(model, noise_seq=ops.PhiloxStream(1))
     # upstream positional AnalyticPredictor signature (quirk Q5) through the Graph-method kernels
     from protein_lig_sedd_amd.model.utils import get_score_fn
     pr = sampling.get_predictor("analytic")(graph, noise)
