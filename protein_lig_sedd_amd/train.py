@@ -201,8 +201,7 @@ class SEDDTrainer:
         """One optimisation step (losses.py:80-115 with accum = 1). Returns the local loss (0-dim device tensor)."""
         fl = self.flat
         fl.g.zero_()
-        if not self.model.training:
-            self.model.train()
+        self.model.train()
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
         loss.backward()
         self.apply_gradients()
@@ -471,8 +470,7 @@ class CrossAttTrainer(SEDDTrainer):
         task = task or self.task
         fl = self.flat
         fl.g.zero_()
-        if not self.model.training:
-            self.model.train()
+        self.model.train()
         out = self.calc_loss(batch, task, t=t, perturbed=perturbed)
         loss = out[0].mean() if task == "joint" else out.mean()
         loss.backward()
