@@ -71,6 +71,18 @@ def test_argument_validation_without_gpu():
     assert L.sedd_gemm_nt(p, 12, p, 12, p, 4, 1, 1, None, 0, None, 0, 4, 4, 12, None) == -2
     assert b"multiples of 8" in L.sedd_last_error()
     assert L.sedd_attn_fwd(p, p, p, p, p, None, 1, 1, 1, 4, 4, 48, 48, 48, 48, 48, 48, 48, None) == -2
+    # fp32 NN / TN products: the k-major operand's extent must be a multiple of 4 floats; fp32 operands give fp32 results
+    assert L.sedd_gemm_nn(p, 8, p, 8, p, 8, 0, 0, None, 0, 4, 6, 8, None) == -2
+    assert b"gemm_nn (fp32)" in L.sedd_last_error()
+    assert L.sedd_gemm_nn_ws(p, 8, p, 8, p, 8, 0, 1, None, 0, 4, 8, 8, None, 0, None) == -2
+    assert L.sedd_gemm_nn_ws(p, 8, p, 8, p, 8, 0, 0, None, 0, 4, 8, 8, None, -1, None) == -1
+    assert L.sedd_gemm_tn(p, 8, p, 8, p, 8, 0, 0, 0, 6, 8, 5, None, 0, None) == -2
+    assert b"gemm_tn (fp32)" in L.sedd_last_error()
+    assert L.sedd_gemm_nn(p, 8, p, 8, p, 8, 0, 0, None, 0, 0, 8, 8, None) == 0     # empty problem
+    assert L.sedd_adamw_ema_double_step(None, None, None, None, None, None, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0,
+                                        0.999, 8, None) == -1                       # step is 1-based
+    assert L.sedd_adamw_ema_double_step(None, None, None, None, None, None, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1,
+                                        0.999, 6, None) == -2                       # n % 4
     assert L.sedd_ln_modulate_fwd(p, p, None, None, None, 0, 0, p, 0, None, None, 4, 2, 4100, None) == -2
     assert L.sedd_ln_bwd_chunks(64 * 512, 512) == 64 * 8   # 64-row chunks from 16384 rows up
     assert L.sedd_ln_bwd_chunks(4 * 512, 512) == 4 * 16     # 32-row chunks below
