@@ -35,6 +35,9 @@ def test_gemm_fp32(M, N, K):
     C0 = C.clone()
     ops.gemm_nt(A, B, out=C, accumulate=True)
     assert rel_err(C, C0.double() + ref) < 2e-6
+    assert rel_err(ops.gemm_nt(A, B, bias=bias, out_dtype=torch.bfloat16).float(), ref + bias.double()) < 4e-3  # bf16 result
+    wide = torch.randn(M, K + 8, device=DEV)
+    assert rel_err(ops.gemm_nt(wide[:, 4:4 + K], B), wide[:, 4:4 + K].double() @ B.double().T) < 2e-6  # row stride > K
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 136), (8, 4608, 128), (64, 64, 8), (512, 1024, 2048),
