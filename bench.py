@@ -159,8 +159,9 @@ def cpu_baseline_cfg1(euler_steps_timed=12):
 
 
 # average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
-# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r2_pmc_hbm_traffic.csv, last row
-GEMM_HBM_BYTES_PER_LAUNCH = 279.4e6
+# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r2g_pmc_hbm_traffic.csv, last row (160 launches
+# per step; 279.4e6 in r2_pmc_hbm_traffic.csv, when the family still held the 26 small adaLN-backward launches of a step)
+GEMM_HBM_BYTES_PER_LAUNCH = 324.3e6
 
 
 def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
@@ -253,9 +254,9 @@ def main():
         trainer.train_step(batches[i % 4])
     sync()
     trainer.reset_allreduce_timing()
-    # HIP events on the launch stream around every 5th launch of each kernel family (5 is coprime to the 186 GEMM
-    # launches of a step, so over the timed steps every launch position is sampled equally often); bracketing every
-    # launch costs 1.2 ms per step (tools/event_overhead.py)
+    # HIP events on the launch stream around every 5th launch of each kernel family (the sampling phase moves on by one
+    # every 97 launches, so over the timed steps every launch position of a step is sampled about equally often whatever
+    # the number of launches per step is); bracketing every launch costs 1.2 ms per step (tools/event_overhead.py)
     ops.PROF = ops.KernelProf(stride=5)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -332,7 +333,7 @@ def main():
                                    "Linear fwd / dgrad / wgrad launch of the step",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": GEMM_HBM_BYTES_PER_LAUNCH if (B, L) == (64, 512) else None,
-                         "traffic_source": "profiles/r2_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
+                         "traffic_source": "profiles/r2g_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
                                            "rocprofv3 --pmc passes of this command, average over the bf16 GEMM launches)",
                          "launches_per_step": n_g / max(args.steps, 1),
                          "timed_sample": "HIP events around every 5th launch of the family, scaled to all launches",

@@ -106,7 +106,7 @@ def cross_block_forward(x, c, other, other_mask, P, n_heads, cos, sin, p_drop, c
     inv = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     keep1 = Lyr.dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
     x1 = ops.gate_residual_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv)
-    st = dict(x=x, c_c=c_c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, pq=pq, pk=pk, pv=pv, o=o, lse=lse, ao=ao,
+    st = dict(x=x, c=c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, pq=pq, pk=pk, pv=pv, o=o, lse=lse, ao=ao,
               a=a, keep1=keep1, x1=x1, inv=inv, cos=cos, sin=sin, seq_axis=seq_axis, ca=None) if save else None
     xm = x1
     if other is not None and "cross_attn.norm.weight" in P:
@@ -210,7 +210,7 @@ def cross_block_backward(dx2, st, P, n_heads):
     ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"], dx,
                         True, G("norm1.weight"), dmod[:, :D], dmod[:, D:2 * D])
     # ---- adaLN
-    dmod_c = dmod if cdt == torch.float32 else ops.cast(dmod, cdt)
-    dc = part_bwd(st["c_c"], dmod_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], 0, 6 * D,
-                  G("adaLN_modulation.weight"), G("adaLN_modulation.bias"), dx_dtype=torch.float32)
+    # (fp32 operands whatever the compute dtype, as in layers.ddit_block_backward: [B, 6D] and [B, C] are fp32 as they stand)
+    dc = part_bwd(st["c"], dmod, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], 0, 6 * D,
+                  G("adaLN_modulation.weight"), G("adaLN_modulation.bias"))
     return dx, dc, d_other, sink.result(list(P.keys()))

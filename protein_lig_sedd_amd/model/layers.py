@@ -202,7 +202,7 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
     x2 = ops.gate_residual_fwd(x1, y, mod[:, 5 * D:6 * D], keep2, inv)
     st = None
     if save:
-        st = dict(x=x, c_c=c_c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
+        st = dict(x=x, c=c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
                   x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, g=g, y=y, keep2=keep2, inv=inv, cos=cos, sin=sin,
                   cu=cu_seqlens)
     return x2, st
@@ -251,9 +251,11 @@ def ddit_block_backward(dx2, st, P, n_heads):
     ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],
                         dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D])
     # ---- adaLN: mod = Linear(c)
-    dmod_c = dmod if cdt == torch.float32 else ops.cast(dmod, cdt)
+    # fp32 operands whatever the compute dtype: dmod [B, 6D] and c [B, C] are fp32 as they stand and a batch is a few dozen
+    # rows, so the exact-fp32 kernels take them as stored (weight gradient from [B, .] row-major, dc against the master
+    # weight with K split over blocks) — the bf16 route needed a cast, a transposed weight copy and a zero-fill per block
     dc, grads["adaLN_modulation.weight"], grads["adaLN_modulation.bias"] = linear_bwd(
-        st["c_c"], dmod_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], dx_dtype=torch.float32)
+        st["c"], dmod, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])
     return dx, dc, grads
 
 
@@ -270,7 +272,7 @@ def final_layer_forward(x, c, P, cdt, save):
     h, mean, rstd = ops.ln_modulate_fwd(x, P["norm_final.weight"].detach(), shift=mod[:, :D], scale=mod[:, D:2 * D],
                                         out_dtype=cdt)
     logits = linear_fwd(h.view(M, D), P["linear.weight"], P["linear.bias"]).view(B, L, -1)
-    st = dict(x=x, c_c=c_c, mod=mod, h=h, mean=mean, rstd=rstd) if save else None
+    st = dict(x=x, c=c, mod=mod, h=h, mean=mean, rstd=rstd) if save else None
     return logits, st
 
 
@@ -289,9 +291,11 @@ def final_layer_backward(dlogits, st, P):
     dw, grads["norm_final.weight"] = _vec_sink(P["norm_final.weight"], D)
     ops.ln_modulate_bwd(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"], st["rstd"], dx,
                         False, dw, dmod[:, :D], dmod[:, D:2 * D])
-    dmod_c = dmod if cdt == torch.float32 else ops.cast(dmod, cdt)
+    # fp32 operands whatever the compute dtype: dmod [B, 6D] and c [B, C] are fp32 as they stand and a batch is a few dozen
+    # rows, so the exact-fp32 kernels take them as stored (weight gradient from [B, .] row-major, dc against the master
+    # weight with K split over blocks) — the bf16 route needed a cast, a transposed weight copy and a zero-fill per block
     dc, grads["adaLN_modulation.weight"], grads["adaLN_modulation.bias"] = linear_bwd(
-        st["c_c"], dmod_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"], dx_dtype=torch.float32)
+        st["c"], dmod, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])
     return dx, dc, grads
 
 
