@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEDD_ABI_VERSION 3
+#define SEDD_ABI_VERSION 4
 
 typedef void* sedd_stream_t; /* hipStream_t */
 
@@ -212,7 +212,8 @@ int sedd_logits_epilogue_bwd(void* dlogits, int dtype, const int64_t* idx, int64
 
 /* Column sums: out[j] (+)= sum_r a[r, j]  (bias gradients); a [M, N] with row stride lda; out fp32 [N].  ws: NULL, or fp32
  * scratch of ceil(M / 128) * N floats — the 128-row blocks then write their partial sums there and a fixed-order fold adds
- * them to out (bit-reproducible); with NULL they add to out with fp32 atomics. */
+ * them to out (bit-reproducible); with NULL they add to out with fp32 atomics.  M <= 8192 with N >= 256 is one launch
+ * that needs neither (a block per 8 columns sums all rows in a fixed order). */
 int sedd_colsum(const void* a, int dtype, int64_t lda, float* out, float* ws, int accumulate, int64_t M, int N,
                 sedd_stream_t stream);
 /* out[N, M] = a[M, N]^T with optional dtype conversion (operand re-layout for the wgrad/dgrad GEMMs). */
