@@ -979,6 +979,9 @@ __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* _
 // (the odd row stride spreads the 8 k-chunks of a wave over all banks), a k-major source as whole float4.
 // gridDim.y > 1 splits K: slice y covers [y * kper, (y + 1) * kper) and parks its partial tile in `slabs`
 // (splitk_fold_kernel adds the slices in order).
+// Measured and not kept: two LDS buffers with the next tile stored half way through the current step's MFMAs and one
+// barrier per step — 3-8 % slower on every shape (8192 x 4096 x 1024 NN: 586 -> 929 us); the doubled LDS halves the blocks
+// a CU can hold, and co-resident blocks are what hides this kernel's store / barrier phases.
 template <typename TO, int TM, int TN, bool AKM, bool BKM, int BK>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb, TO* __restrict__ C,
