@@ -148,8 +148,13 @@ class _GraphedStep:
                 fn(self.x, self.t, self.u)
         torch.cuda.current_stream(x.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.x.copy_(fn(self.x, self.t, self.u))
+        try:
+            with torch.cuda.graph(self.graph):
+                self.x.copy_(fn(self.x, self.t, self.u))
+        except RuntimeError as e:  # (torch.AcceleratorError is a RuntimeError)
+            raise RuntimeError("hip_graph=True: the predictor update could not be captured — proj_fun or the model call "
+                               "does host-side work under capture (a Python list / bool-mask index, .item(), a "
+                               f"host-to-device copy ...): {e}") from e
 
     def run(self, x, t_seq, noise_seq, steps):
         self.x.copy_(x)

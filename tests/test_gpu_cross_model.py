@@ -272,6 +272,23 @@ def test_g18_conditional_sampling_bit_exact(golden):
     out = proj_fun(sampler(model, noise_seq=seq))
     assert int((out.cpu() != g["infill_out"]).sum()) == 0
     assert torch.equal(out[:, locs], ids)
+    # the same run with the update (clamp included) replayed as a HIP graph
+    # (indexing with a Python list copies the index from the host on every call, which a capture refuses: the clamp has
+    # to be device-side work)
+    loc_t = torch.tensor(locs, device=DEV)
+
+    def proj_dev(x):
+        x[:, loc_t] = ids
+        return x
+
+    gsampler = sampling.get_pc_sampler(graph_lib.Absorbing(tokens), noise, (B, L), "euler", steps, denoise=True, eps=1e-5,
+                                       device=DEV, proj_fun=proj_dev, hip_graph=True)
+    assert int((proj_fun(gsampler(model, noise_seq=seq)).cpu() != g["infill_out"]).sum()) == 0
+    bad = sampling.get_pc_sampler(graph_lib.Absorbing(tokens), noise, (B, L), "euler", steps, device=DEV, proj_fun=proj_fun,
+                                  hip_graph=True)
+    with pytest.raises(RuntimeError, match="could not be captured"):
+        bad(model, noise_seq=seq)
+    assert int((sampler(model, noise_seq=seq).cpu() != gsampler(model, noise_seq=seq).cpu()).sum()) == 0  # still usable
     # the Analytic predictor honours the same clamp (no golden: the reference's loop cannot call it, quirk Q5)
     out = proj_fun(sampling.get_pc_sampler(graph_lib.Absorbing(tokens), noise, (B, L), "analytic", steps, device=DEV,
                                            proj_fun=proj_fun)(model))
@@ -288,6 +305,9 @@ def test_g18_conditional_sampling_bit_exact(golden):
         seq = [u.to(DEV) for u in g[tag + "_u"]] + [g[tag + "_u_denoise"].to(DEV)]
         out = sampler(cm, noise_seq=seq, **kw)
         assert int((out.cpu() != g[tag + "_out"]).sum()) == 0, tag
+        gsampler = sampling.get_pc_sampler(gr, noise, (B, Lx), "euler", steps, denoise=True, eps=1e-5, device=DEV,
+                                           hip_graph=True)
+        assert int((gsampler(cm, noise_seq=seq, **kw).cpu() != g[tag + "_out"]).sum()) == 0, tag + " (graph)"
     assert cm._ctx_step is None and cm._ctx_cache == {}  # the per-step context cache does not outlive a run
 
 
