@@ -992,47 +992,54 @@ __global__ void __launch_bounds__(TPB) embedding_bwd_large_kernel(const float* _
     }
 }
 // "owner computes": block (64 columns, vocabulary row v) adds the rows of dout whose token is v — no atomics, no scratch,
-// fixed order.  Each of the 4 waves scans its own 64-index segments of the token list (one index per lane, the matches
-// collected with a ballot) and keeps a running sum per column, four matched rows in flight at a time; the four partial
-// sums meet in LDS in wave order.  Under the absorbing graph half the tokens of a batch are the mask token, so ONE
-// vocabulary row owns a thousand rows of dout: its chain is split 4 ways here and 16 column blocks share it (a form with
-// one serial chain per 1024 columns took 1.2 ms on that row; the first form, which tested every index in every thread,
-// 290-360 us on every shape).  The scan is V * M / 64 wave passes, so this serves the shapes where V * M is small
-// (the cross model: 2365 x 512, 37 x 2048).
-__global__ void __launch_bounds__(TPB) embedding_bwd_owner_kernel(const float* __restrict__ dout,
-                                                                  const int64_t* __restrict__ idx,
-                                                                  float* __restrict__ dtable, int64_t M, int D) {
-    static_assert(TPB == 256, "four waves");
-    __shared__ float part[4][64];
+// fixed order.  Each of the block's 4 or 16 waves scans its own 64-index segments of the token list (one index per lane,
+// the matches collected with a ballot) and keeps a running sum per column, eight matched rows in flight at a time; the
+// partial sums meet in LDS in wave order.  Under the absorbing graph half the tokens of a batch are the mask token, so
+// ONE vocabulary row owns half the rows of dout: its chain is split over the waves and D / 64 column blocks share it (a
+// form with one serial chain per 1024 columns took 1.2 ms on that row at M = 2048; the first form, which tested every
+// index in every thread, 290-360 us on every shape).  Every column block scans the whole token list, V * M * D / 4096
+// wave passes in all, so this serves the shapes where V * M is small (the cross model: 2365 x 512 and 37 x 2048, 27 and
+// 15 us; config_large's 2397 x 16384 took 494 us and stays with the atomic kernel).
+#define EMB_OWNER_FLIGHT 8
+template <int EMB_OWNER_WAVES>
+__global__ void __launch_bounds__(64 * EMB_OWNER_WAVES) embedding_bwd_owner_kernel(const float* __restrict__ dout,
+                                                                                   const int64_t* __restrict__ idx,
+                                                                                   float* __restrict__ dtable, int64_t M,
+                                                                                   int D) {
+    __shared__ float part[EMB_OWNER_WAVES][64];
     const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     const bool live = col < D;
     const float* src = dout + (live ? col : 0);
     float s = 0.f;
     int any = 0;
-    for (int64_t r0 = (int64_t)wave * 64; r0 < M; r0 += TPB) {
+    for (int64_t r0 = (int64_t)wave * 64; r0 < M; r0 += 64 * EMB_OWNER_WAVES) {
         const int64_t r = r0 + lane;
         unsigned long long mk = __ballot(r < M && idx[r] == v);  // (wave-uniform)
         any |= mk != 0;
         while (mk) {
-            int b[4];
+            int b[EMB_OWNER_FLIGHT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < EMB_OWNER_FLIGHT; ++q) {
                 b[q] = mk ? __builtin_ctzll(mk) : -1;
                 mk &= mk - 1;  // (0 stays 0)
             }
-            float x[4];
+            float x[EMB_OWNER_FLIGHT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = (b[q] >= 0 && live) ? src[(r0 + b[q]) * D] : 0.f;
+            for (int q = 0; q < EMB_OWNER_FLIGHT; ++q) x[q] = (b[q] >= 0 && live) ? src[(r0 + b[q]) * D] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < EMB_OWNER_FLIGHT; ++q)
                 if (b[q] >= 0) s += x[q];
         }
     }
     part[wave][lane] = s;
     any = __syncthreads_or(any);
-    if (wave == 0 && live && any)
-        dtable[(int64_t)v * D + col] += ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (wave == 0 && live && any) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < EMB_OWNER_WAVES; ++w) t += part[w][lane];
+        dtable[(int64_t)v * D + col] += t;
+    }
 }
 extern "C" int64_t sedd_embedding_bwd_ws_floats(int64_t M, int D, int V) {
     return (V <= 32 && D % 4 == 0) ? ((M + EMB_ROWS - 1) / EMB_ROWS) * (int64_t)V * D : 0;
@@ -1043,8 +1050,13 @@ extern "C" int sedd_embedding_bwd(const float* dout, const int64_t* idx, float* 
     if (M == 0) return SEDD_OK;
     SEDD_CHECK_ARG(dout && idx && dtable, "embedding_bwd: null pointer");
     if (!(V <= 32 && ws) && (int64_t)V * M <= (1 << 22) && V <= 65535) {
-        hipLaunchKernelGGL(embedding_bwd_owner_kernel, dim3((D + 63) / 64, (unsigned)V), dim3(TPB), 0,
-                           (hipStream_t)stream, dout, idx, dtable, M, D);
+        // (a wave per 128 tokens, 4 or 16 to the block: idle waves of a 1024-thread block cost more than they scan)
+        if (M <= 1024)
+            hipLaunchKernelGGL(embedding_bwd_owner_kernel<4>, dim3((D + 63) / 64, (unsigned)V), dim3(256), 0,
+                               (hipStream_t)stream, dout, idx, dtable, M, D);
+        else
+            hipLaunchKernelGGL(embedding_bwd_owner_kernel<16>, dim3((D + 63) / 64, (unsigned)V), dim3(1024), 0,
+                               (hipStream_t)stream, dout, idx, dtable, M, D);
     } else if (V <= 32 && D % 4 == 0 && ((uintptr_t)dout & 15) == 0) {
         const int nblk = (int)((M + EMB_ROWS - 1) / EMB_ROWS);
         hipLaunchKernelGGL(embedding_bwd_v32_kernel, dim3((D + 255) / 256, (unsigned)nblk), dim3(TPB), 0,
