@@ -9,7 +9,8 @@ from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandD
 from protein_lig_sedd_amd.train import CrossAttTrainer
 ns = types.SimpleNamespace
 dev = torch.device("cuda", 0)
-D, H, C, nb, Lp, Ll = 1024, 32, 128, 12, 512, 128
+D, H, C, nb = 1024, 32, 128, 12
+Lp, Ll = int(os.environ.get("CFG3_LP", "512")), int(os.environ.get("CFG3_LL", "128"))
 B = int(os.environ.get("CFG3_BATCH", "4"))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for name in os.environ.get("CFG3_DTYPES", "fp32,bf16").split(","):
