@@ -198,9 +198,13 @@ def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps
                                                prot_indices=prot_indices, lig_indices=lig_indices, u=us)
 
                 u0 = None if noise_seq is None else noise_seq[0]
+                # (parameter versions: a capture holds the compute-dtype weight copies that were cached when it was made;
+                # weights replaced through autograd-visible writes — load_state_dict, ema.copy_to — bump a version and
+                # force a new capture, the trainer's in-place flat-buffer updates keep the cached views current)
+                wsig = sum(p._version for p in model.parameters()) if hasattr(model, "parameters") else 0
                 key = (id(model), task, None if prot_indices is None else prot_indices.data_ptr(),
                        None if lig_indices is None else lig_indices.data_ptr(), tuple(x.shape),
-                       None if u0 is None else tuple(u0.shape))
+                       None if u0 is None else tuple(u0.shape), wsig)
                 if key not in graphed:
                     mark(None)  # (the per-step context cache is host state: the captured step recomputes the context)
                     graphed.clear()

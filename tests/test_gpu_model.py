@@ -207,6 +207,15 @@ def test_g13_pc_sampler_bit_exact(golden):
     with pytest.raises(ValueError):
         from protein_lig_sedd_amd import ops
         gs(model, noise_seq=ops.PhiloxStream(1))
+    # a bf16 model whose weights are replaced after a capture: the next run must see the new weights (new capture)
+    mb = _SEDD(sedd_config(D, H, C, nb, tokens), compute_dtype=torch.bfloat16).to(DEV)
+    load_sd(mb, seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=13, std=0.1))
+    seq = [u.to(DEV) for u in g["euler_u"]] + [g["euler_u_denoise"].to(DEV)]
+    eager = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, device=DEV)
+    gs = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, device=DEV, hip_graph=True)
+    assert torch.equal(gs(mb, noise_seq=seq), eager(mb, noise_seq=seq))
+    load_sd(mb, seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=14, std=0.1))
+    assert torch.equal(gs(mb, noise_seq=seq), eager(mb, noise_seq=seq))
     # upstream positional AnalyticPredictor signature (quirk Q5) through the Graph-method kernels
     from protein_lig_sedd_amd.model.utils import get_score_fn
     pr = sampling.get_predictor("analytic")(graph, noise)
