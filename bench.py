@@ -164,6 +164,43 @@ def cpu_baseline_cfg1(euler_steps_timed=12):
 GEMM_HBM_BYTES_PER_LAUNCH = 324.3e6
 
 
+def gpu_cfg1(dev):
+    """BASELINE configs[0] on the GPU, beside the CPU figures above: the same tiny model (fp32, as on the CPU), one train
+    step and the whole 128-step Euler sampler + denoise — eager, and with the predictor update replayed as a HIP graph."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib, sampling
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    ns = types.SimpleNamespace
+    B, L, steps = 8, 128, 128
+    cfg = ns(tokens=25, graph=ns(type="absorb"),
+             model=ns(hidden_size=768, cond_dim=128, n_heads=8, n_blocks=8, dropout=0.1, scale_by_sigma=True))
+    model = _SEDD(cfg, compute_dtype=torch.float32).to(dev)
+    randomize(model, 1)
+    graph, noise = graph_lib.Absorbing(25), noise_lib.LogLinearNoise(eps=1e-3).to(dev)
+    out = {}
+    for hg in (False, True):
+        fn = sampling.get_pc_sampler(graph, noise, (B, L), "euler", steps, denoise=True, eps=1e-5, device=dev, hip_graph=hg)
+        fn(model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(model)
+        torch.cuda.synchronize()
+        out["euler_128_steps_plus_denoise_s" + ("_hip_graph" if hg else "")] = time.perf_counter() - t0
+    tr = SEDDTrainer(model, noise, graph, dict(lr=3e-4, warmup=100, grad_clip=1.0), ema_decay=0.9999, world_size=1)
+    x = torch.randint(0, 25, (B, L), device=dev)
+    for _ in range(3):
+        tr.train_step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tr.train_step(x)
+    torch.cuda.synchronize()
+    out["train_step_s"] = (time.perf_counter() - t0) / 10
+    out["train_tokens_per_s"] = B * L / out["train_step_s"]
+    out["sampled_seqs_per_s"] = B / out["euler_128_steps_plus_denoise_s"]
+    return out
+
+
 def hbm_kernels_cfg5(graph, dev, B=512, L=1024, iters=20):
     """the HBM-bound loss / sampling kernels at the BASELINE configs[4] per-GPU shard size (512 x 1024 rows, V = 26,
     bf16 log-scores): algorithmic bytes / HIP-event time on the launch stream."""
@@ -345,6 +382,7 @@ def main():
             out["sampling"] = samp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["cfg1"]["this_gpu"] = gpu_cfg1(dev)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
