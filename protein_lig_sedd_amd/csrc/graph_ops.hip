@@ -602,7 +602,10 @@ __global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step
 // 4-6 us serial chain per wave behind which the block's next stage waits (tools/pred_bench.py has the harness).  Two
 // things found on the way apply here: `__syncthreads()` = vmcnt(0) + barrier drains every in-flight LDS-DMA, and LDS
 // reads placed under the `j < V` guards compile to one round trip per element (the row is now read unguarded, in one
-// batch: 29.7 -> 28.2 us).
+// batch: 29.7 -> 28.2 us).  An upper bound on what cheaper arithmetic could buy (v_log_f32 * ln 2 and v_rcp_f32 in place of
+// the compensated log and the IEEE division, tokens no longer bit-exact; a certified version would fall back to the exact
+// scan on near-ties): 28.5 -> 25.8 us — and with only 10 % of the rows doing any arithmetic the kernel still takes 23 us, so
+// the VALU count explains a third of the gap to the DMA-only time at most; not pursued.
 // Philox4x32-10 (Salmon et al., SC'11; the counter-based generator behind curand / torch's device RNG): four 32-bit words
 // from a 128-bit counter and a 64-bit key.  sedd_predictor_step_philox draws the uniform of (row, vocabulary slot j) as
 // word (j & 3) of philox(counter = {row_lo, row_hi, j >> 2, offset}, key = {seed_lo, seed_hi}), u = (word >> 8) * 2^-24
