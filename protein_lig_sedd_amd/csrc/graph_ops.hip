@@ -605,7 +605,11 @@ __global__ void __launch_bounds__(TPB) predictor_step_kernel(int graph, int step
 // batch: 29.7 -> 28.2 us).  An upper bound on what cheaper arithmetic could buy (v_log_f32 * ln 2 and v_rcp_f32 in place of
 // the compensated log and the IEEE division, tokens no longer bit-exact; a certified version would fall back to the exact
 // scan on near-ties): 28.5 -> 25.8 us — and with only 10 % of the rows doing any arithmetic the kernel still takes 23 us, so
-// the VALU count explains a third of the gap to the DMA-only time at most; not pursued.
+// the VALU count explains a third of the gap to the DMA-only time at most; not pursued.  Bytes are not the limit either:
+// staging only the chunks that touch a masked row (the state read first, the DMA exec-masked by a per-row flag; tokens
+// still bit-exact) moved 45 % fewer bytes at the bench's 50 % mask fraction and ran 32.2 us instead of 28.5 (26.6 vs 25.4 at
+// 10 %).  What remains is the serial chain of a block (scalars -> DMA -> wait -> per-row arithmetic -> store, ~9 us) times
+// the 2.7 rounds of blocks that 40 KB of LDS per block lets the chip hold.
 // Philox4x32-10 (Salmon et al., SC'11; the counter-based generator behind curand / torch's device RNG): four 32-bit words
 // from a 128-bit counter and a 64-bit key.  sedd_predictor_step_philox draws the uniform of (row, vocabulary slot j) as
 // word (j & 3) of philox(counter = {row_lo, row_hi, j >> 2, offset}, key = {seed_lo, seed_hi}), u = (word >> 8) * 2^-24
