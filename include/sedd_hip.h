@@ -100,6 +100,22 @@ int sedd_transp_transition(int graph, const int64_t* x, const float* sigma, floa
 
 /* ------------------------------------------------------------------------------------------ model: pointwise */
 
+/* SEDD.forward's pooled conditioners (model/transformer.py:289-301; BatchNorm1d modules :259-260):
+ * out = mean([c, BN_e(e), BN_m(m)]) over the terms whose input pointer is non-NULL; c, e, m, out fp32 [B, C] (e / m
+ * are the outputs of esm_proj / mol_proj, computed with sedd_gemm_nt).  training != 0: batch statistics (biased
+ * variance), running statistics updated in place with `momentum` (unbiased variance), B >= 2 required as in torch;
+ * training == 0: the running statistics.  *_mean / *_rstd [C] receive the statistics used (saved for the backward). */
+int sedd_cond_combine_fwd(const float* c, const float* e, const float* e_w, const float* e_b, float* e_rmean,
+                          float* e_rvar, float* e_mean, float* e_rstd, const float* m, const float* m_w,
+                          const float* m_b, float* m_rmean, float* m_rvar, float* m_mean, float* m_rstd, float* out,
+                          int training, float momentum, float eps, int B, int C, sedd_stream_t stream);
+/* autograd backward of the above: dc = dout / n; de / dm = BatchNorm backward of dout / n (NULL: not needed);
+ * *_dw / *_db [C] = BatchNorm weight / bias gradients (accumulate != 0: added to what the buffers hold). */
+int sedd_cond_combine_bwd(const float* dout, const float* e, const float* e_w, const float* e_mean,
+                          const float* e_rstd, float* de, float* e_dw, float* e_db, const float* m, const float* m_w,
+                          const float* m_mean, const float* m_rstd, float* dm, float* m_dw, float* m_db, float* dc,
+                          int training, int accumulate, int B, int C, sedd_stream_t stream);
+
 /* model/transformer.py:70-89: out[b] = [cos(sigma_b f_k), sin(sigma_b f_k)], f_k = exp(-ln(1e4) k / half). */
 int sedd_timestep_embedding(const float* sigma, float* out, int B, int dim, sedd_stream_t stream);
 /* SiLU forward / backward (transformer.py:62-66, :285), fp32, n elements. dx = dy * silu'(x). */

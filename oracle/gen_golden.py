@@ -913,6 +913,94 @@ def g19_varlen_block():
     save("g19_varlen_block", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G20
+def sedd_cond_config(hidden, heads, cond, blocks, tokens, esm_dim, mol_dim):
+    cfg = sedd_config(hidden, heads, cond, blocks, tokens=tokens)
+    cfg.model.esm_dim, cfg.model.molformer_dim = esm_dim, mol_dim
+    return cfg
+
+
+def _load_sedd_cond(model, seed):
+    """seeded weights + BatchNorm scales moved to 1 + N(0, 0.02) and non-trivial running statistics (the tests apply
+    the same recipe by name)."""
+    load_seeded(model, seed=seed)
+    with torch.no_grad():
+        for bn in (model.esm_norm, model.mol_norm):
+            bn.weight.add_(1.0)
+        g = torch.Generator().manual_seed(seed + 7)
+        for bn in (model.esm_norm, model.mol_norm):
+            bn.running_mean.copy_(torch.randn(bn.running_mean.shape, generator=g) * 0.05)
+            bn.running_var.copy_(1.0 + 0.3 * torch.rand(bn.running_var.shape, generator=g))
+
+
+def g20_sedd_conditioned():
+    """`SEDD` (transformer.py:240-325) — the class north_star names — WITH its pooled conditioners: esm_proj / mol_proj +
+    BatchNorm1d + mean over [c, esm_c, mol_c] (:289-301), as the DDP trainer calls it (run_train_ddp_protlig_transf.py:284
+    passes esm_cond / mol_cond).  Cases: 'train' (BatchNorm batch statistics + running-stat update; logits, loss, all
+    gradients), 'eval' (running statistics), 'esm' (mol_cond=None: the two-term mean), and 'large' = the model dims of
+    configs/config_large.yaml with its 2396-token vocabulary at L 1024 (2 blocks; logits stored on a row subsample)."""
+    out = {}
+    noise = noise_lib.LogLinearNoise(eps=1e-3)
+    # ---- mini: every branch, with gradients
+    cfg = sedd_cond_config(128, 4, 64, 2, 25, 40, 48)
+    graph = graph_lib.Absorbing(25)
+    model = ref_tf.SEDD(cfg)
+    _load_sedd_cond(model, seed=20)
+    B, L = 5, 48
+    x0, t, u = _loss_inputs(B, L, 26, 2020)
+    g = torch.Generator().manual_seed(2021)
+    esm, mol = torch.randn(B, 40, generator=g), torch.randn(B, 48, generator=g) * 0.7 + 0.1
+    sigma, dsigma = noise(t)
+    xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 25), x0)
+    out.update({"mini_x0": x0, "mini_t": t, "mini_xt": xt, "mini_sigma": sigma, "mini_esm": esm, "mini_mol": mol,
+                "mini_cfg": np.array([128, 4, 64, 2, 25, 40, 48])})
+    for bn, nm in ((model.esm_norm, "esm_norm"), (model.mol_norm, "mol_norm")):
+        out[f"mini_{nm}.running_mean0"], out[f"mini_{nm}.running_var0"] = bn.running_mean.clone(), bn.running_var.clone()
+    model.eval()
+    out["mini_eval_logits"] = quiet(model, xt, sigma, esm, mol)
+    out["mini_esm_eval_logits"] = quiet(model, xt, sigma, esm, None)
+    out["mini_none_eval_logits"] = quiet(model, xt, sigma)
+    model.train()
+    logits = quiet(model, xt, sigma, esm, mol)
+    se = graph.score_entropy(logits, sigma[:, None], xt, x0)
+    loss = (dsigma[:, None] * se).mean()
+    model.zero_grad()
+    loss.backward()
+    out["mini_train_logits"], out["mini_train_loss"] = logits, loss
+    for n, p in model.named_parameters():
+        out["mini_train_grad." + n] = p.grad
+    for bn, nm in ((model.esm_norm, "esm_norm"), (model.mol_norm, "mol_norm")):
+        out[f"mini_{nm}.running_mean1"], out[f"mini_{nm}.running_var1"] = bn.running_mean.clone(), bn.running_var.clone()
+        out[f"mini_{nm}.num_batches_tracked1"] = bn.num_batches_tracked.clone()
+    # a second training forward with only the ESM conditioner: the molecule BatchNorm must stay untouched
+    logits2 = quiet(model, xt, sigma, esm, None)
+    out["mini_esm_train_logits"] = logits2
+    out["mini_esm_norm.running_mean2"] = model.esm_norm.running_mean.clone()
+    out["mini_mol_norm.running_mean2"] = model.mol_norm.running_mean.clone()
+    # ---- large: configs/config_large.yaml dims (D 1024, 16 heads, cond 128, tokens 2396, L 1024, esm 640 / mol 768), 2 blocks
+    cfg = sedd_cond_config(1024, 16, 128, 2, 2396, 640, 768)
+    graph = graph_lib.Absorbing(2396)
+    model = ref_tf.SEDD(cfg)
+    _load_sedd_cond(model, seed=24)
+    model.eval()
+    B, L = 2, 1024
+    x0, t, u = _loss_inputs(B, L, 2397, 2024)
+    g = torch.Generator().manual_seed(2025)
+    esm, mol = torch.randn(B, 640, generator=g), torch.randn(B, 768, generator=g)
+    sigma, dsigma = noise(t)
+    xt = torch.where(u < 1 - (-sigma[:, None]).exp(), torch.full_like(x0, 2396), x0)
+    with torch.no_grad():
+        logits = quiet(model, xt, sigma, esm, mol)
+        se = graph.score_entropy(logits, sigma[:, None], xt, x0)
+        loss = (dsigma[:, None] * se).mean()
+    rows = torch.arange(0, L, 37)
+    out.update({"large_x0": x0, "large_t": t, "large_xt": xt, "large_sigma": sigma, "large_esm": esm, "large_mol": mol,
+                "large_cfg": np.array([1024, 16, 128, 2, 2396, 640, 768]), "large_rows": rows,
+                "large_logits_rows": logits[:, rows], "large_loss": loss, "large_se": se,
+                "large_logits_rowsum": logits.double().sum(-1).float()})
+    save("g20_sedd_conditioned", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -921,7 +1009,7 @@ def main():
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
                g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule,
                g16_cross_train_trajectory, g17_bf16_autocast, g18_conditional_sampling,
-               g19_varlen_block):
+               g19_varlen_block, g20_sedd_conditioned):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

@@ -356,10 +356,48 @@ def logits_epilogue(x, sigma, indices, scale_by_sigma=True):
     return torch.scatter(x, -1, indices[..., None], torch.zeros_like(x[..., :1]))
 
 
-def sedd_forward(sd, indices, sigma, n_heads, n_blocks, scale_by_sigma=True, bf16=False):
-    """_SEDD.forward (transformer.py:365-392)."""
+def batchnorm1d(x, w, b, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm1d on [B, C] (transformer.py:259-260,292,298).  training: batch statistics (biased variance in the
+    normalisation, unbiased in the running update); eval: the running statistics.  Returns (y, new running_mean, new
+    running_var); the inputs are not modified."""
+    if training:
+        if x.shape[0] < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        mean = x.mean(0)
+        var = ((x - mean) ** 2).mean(0)
+        n = x.shape[0]
+        rm = (1 - momentum) * running_mean + momentum * mean.detach()
+        rv = (1 - momentum) * running_var + momentum * var.detach() * (n / (n - 1))
+    else:
+        mean, var, rm, rv = running_mean, running_var, running_mean, running_var
+    return (x - mean) / torch.sqrt(var + eps) * w + b, rm, rv
+
+
+def sedd_conditioner(sd, c, esm_cond=None, mol_cond=None, training=False, bn_state=None):
+    """SEDD.forward's pooled conditioners (transformer.py:289-301): c' = mean([c, BN(esm_proj(esm)), BN(mol_proj(mol))])
+    over the terms that are given; fp32 (outside the autocast region).  bn_state: dict of running statistics, updated
+    in place in training mode (default: the entries of sd)."""
+    st = sd if bn_state is None else bn_state
+    conds = [c]
+    for cond, proj, norm in ((esm_cond, "esm_proj", "esm_norm"), (mol_cond, "mol_proj", "mol_norm")):
+        if cond is None:
+            continue
+        h = F.linear(cond, sd[proj + ".weight"], sd[proj + ".bias"])
+        y, rm, rv = batchnorm1d(h, sd[norm + ".weight"], sd[norm + ".bias"], st[norm + ".running_mean"],
+                                st[norm + ".running_var"], training)
+        if training:
+            st[norm + ".running_mean"], st[norm + ".running_var"] = rm, rv
+        conds.append(y)
+    return torch.mean(torch.stack(conds), dim=0)
+
+
+def sedd_forward(sd, indices, sigma, n_heads, n_blocks, scale_by_sigma=True, bf16=False, esm_cond=None, mol_cond=None,
+                 training=False, bn_state=None):
+    """_SEDD.forward (transformer.py:365-392); with esm_cond / mol_cond: SEDD.forward (:277-325)."""
     x = F.embedding(indices, sd["vocab_embed.embedding.weight"])
     c = sigma_cond(sd, sigma)
+    if esm_cond is not None or mol_cond is not None:
+        c = sedd_conditioner(sd, c, esm_cond, mol_cond, training, bn_state)
     for i in range(n_blocks):
         x = ddit_block(sd, f"blocks.{i}.", x, c, n_heads, bf16)
     x = final_layer(sd, "output_layer.", x, c, bf16)

@@ -30,6 +30,8 @@ SIGNATURES = {
     "sedd_staggered_score": "ippplli" + "p",
     "sedd_transp_transition": "ippplli" + "p",
     "sedd_timestep_embedding": "ppiip",
+    "sedd_cond_combine_fwd": "pppppppp" + "ppppppp" + "p" + "iffiip",
+    "sedd_cond_combine_bwd": "pppppppp" + "ppppppp" + "p" + "iiiip",
     "sedd_silu_fwd": "pplp",
     "sedd_silu_bwd": "ppplp",
     "sedd_embedding_fwd": "pppliip",

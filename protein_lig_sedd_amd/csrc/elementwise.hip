@@ -872,6 +872,141 @@ extern "C" int sedd_silu_bwd(const float* x, const float* dy, float* dx, int64_t
     return launch_act<3>(x, dy, dx, SEDD_F32, n, stream, "silu_bwd");
 }
 
+// ============================================================================== pooled conditioners of SEDD
+// transformer.py:289-301: c' = mean([c, BN(esm_proj(esm)), BN(mol_proj(mol))]) over the terms that are given, BN =
+// nn.BatchNorm1d over the batch axis (:259-260).  [B, C] with C = cond_dim: latency-sized, one thread per column.
+struct CondTerm {
+    const float* x;      // [B, C] projection output (NULL: term absent)
+    const float* w;      // [C] BatchNorm weight
+    const float* b;      // [C] BatchNorm bias
+    float* rmean;        // [C] running mean (updated in training)
+    float* rvar;         // [C] running variance
+    float* mean;         // [C] statistics used (saved for the backward)
+    float* rstd;
+    float* dx;           // backward: [B, C]
+    float* dw;           // backward: [C]
+    float* db;
+};
+
+__global__ void __launch_bounds__(64) cond_combine_fwd_kernel(const float* __restrict__ c, CondTerm t0, CondTerm t1,
+                                                              float* __restrict__ out, int training, float momentum,
+                                                              float eps, int B, int C) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= C) return;
+    const CondTerm ts[2] = {t0, t1};
+    float mean[2], rstd[2], w[2], b[2];
+    int n = 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const CondTerm& t = ts[k];
+        mean[k] = 0.f; rstd[k] = 0.f; w[k] = 0.f; b[k] = 0.f;
+        if (!t.x) continue;
+        ++n;
+        if (training) {
+            float s = 0.f;
+            for (int r = 0; r < B; ++r) s += t.x[(int64_t)r * C + col];
+            const float m = s / (float)B;
+            float v = 0.f;
+            for (int r = 0; r < B; ++r) { const float d = t.x[(int64_t)r * C + col] - m; v += d * d; }
+            const float var = v / (float)B;
+            mean[k] = m;
+            rstd[k] = 1.0f / sqrtf(var + eps);
+            t.rmean[col] = (1.0f - momentum) * t.rmean[col] + momentum * m;
+            t.rvar[col] = (1.0f - momentum) * t.rvar[col] + momentum * (v / (float)(B - 1));
+        } else {
+            mean[k] = t.rmean[col];
+            rstd[k] = 1.0f / sqrtf(t.rvar[col] + eps);
+        }
+        t.mean[col] = mean[k];
+        t.rstd[col] = rstd[k];
+        w[k] = t.w[col];
+        b[k] = t.b[col];
+    }
+    const float inv_n = 1.0f / (float)n;
+    for (int r = 0; r < B; ++r) {
+        const int64_t i = (int64_t)r * C + col;
+        float acc = c[i];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (ts[k].x) acc += (ts[k].x[i] - mean[k]) * rstd[k] * w[k] + b[k];
+        out[i] = acc * inv_n;
+    }
+}
+
+__global__ void __launch_bounds__(64) cond_combine_bwd_kernel(const float* __restrict__ dout, CondTerm t0, CondTerm t1,
+                                                              float* __restrict__ dc, int training, int accumulate,
+                                                              int B, int C) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= C) return;
+    const CondTerm ts[2] = {t0, t1};
+    const float inv_n = 1.0f / (float)(1 + (t0.x != nullptr) + (t1.x != nullptr));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const CondTerm& t = ts[k];
+        if (!t.x) continue;
+        const float m = t.mean[col], rs = t.rstd[col], w = t.w[col];
+        float sdy = 0.f, sdyx = 0.f;
+        for (int r = 0; r < B; ++r) {
+            const int64_t i = (int64_t)r * C + col;
+            const float dy = dout[i] * inv_n;
+            sdy += dy;
+            sdyx += dy * ((t.x[i] - m) * rs);
+        }
+        t.dw[col] = (accumulate ? t.dw[col] : 0.f) + sdyx;
+        t.db[col] = (accumulate ? t.db[col] : 0.f) + sdy;
+        if (t.dx) {
+            const float invB = 1.0f / (float)B;
+            for (int r = 0; r < B; ++r) {
+                const int64_t i = (int64_t)r * C + col;
+                const float dy = dout[i] * inv_n;
+                t.dx[i] = training ? w * rs * (dy - invB * sdy - (t.x[i] - m) * rs * (invB * sdyx)) : dy * w * rs;
+            }
+        }
+    }
+    if (dc)
+        for (int r = 0; r < B; ++r) dc[(int64_t)r * C + col] = dout[(int64_t)r * C + col] * inv_n;
+}
+
+static bool cond_term_ok(const CondTerm& t, bool bwd) {
+    if (!t.x) return true;
+    return bwd ? (t.w && t.mean && t.rstd && t.dw && t.db) : (t.w && t.b && t.rmean && t.rvar && t.mean && t.rstd);
+}
+
+extern "C" int sedd_cond_combine_fwd(const float* c, const float* e, const float* e_w, const float* e_b, float* e_rmean,
+                                     float* e_rvar, float* e_mean, float* e_rstd, const float* m, const float* m_w,
+                                     const float* m_b, float* m_rmean, float* m_rvar, float* m_mean, float* m_rstd,
+                                     float* out, int training, float momentum, float eps, int B, int C,
+                                     sedd_stream_t stream) {
+    SEDD_CHECK_ARG(B >= 0 && C > 0, "cond_combine_fwd: bad sizes B=%d C=%d", B, C);
+    if (B == 0) return SEDD_OK;
+    SEDD_CHECK_ARG(!(training && B < 2 && (e || m)),
+                   "cond_combine_fwd: Expected more than 1 value per channel when training, got input size [%d, %d]", B, C);
+    SEDD_CHECK_ARG(momentum >= 0.f && momentum <= 1.f && eps > 0.f, "cond_combine_fwd: bad momentum / eps");
+    CondTerm t0{e, e_w, e_b, e_rmean, e_rvar, e_mean, e_rstd, nullptr, nullptr, nullptr};
+    CondTerm t1{m, m_w, m_b, m_rmean, m_rvar, m_mean, m_rstd, nullptr, nullptr, nullptr};
+    SEDD_CHECK_ARG(c && out && cond_term_ok(t0, false) && cond_term_ok(t1, false), "cond_combine_fwd: null pointer");
+    hipLaunchKernelGGL(cond_combine_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, c, t0, t1, out,
+                       training, momentum, eps, B, C);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
+extern "C" int sedd_cond_combine_bwd(const float* dout, const float* e, const float* e_w, const float* e_mean,
+                                     const float* e_rstd, float* de, float* e_dw, float* e_db, const float* m,
+                                     const float* m_w, const float* m_mean, const float* m_rstd, float* dm, float* m_dw,
+                                     float* m_db, float* dc, int training, int accumulate, int B, int C,
+                                     sedd_stream_t stream) {
+    SEDD_CHECK_ARG(B >= 0 && C > 0, "cond_combine_bwd: bad sizes B=%d C=%d", B, C);
+    if (B == 0) return SEDD_OK;
+    CondTerm t0{e, e_w, nullptr, nullptr, nullptr, (float*)e_mean, (float*)e_rstd, de, e_dw, e_db};
+    CondTerm t1{m, m_w, nullptr, nullptr, nullptr, (float*)m_mean, (float*)m_rstd, dm, m_dw, m_db};
+    SEDD_CHECK_ARG(dout && cond_term_ok(t0, true) && cond_term_ok(t1, true), "cond_combine_bwd: null pointer");
+    hipLaunchKernelGGL(cond_combine_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, dout, t0, t1, dc,
+                       training, accumulate, B, C);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
 // ======================================================================================= timestep embedding
 // transformer.py:70-89
 __global__ void __launch_bounds__(TPB) timestep_embedding_kernel(const float* __restrict__ sigma,

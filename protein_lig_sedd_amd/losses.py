@@ -33,7 +33,12 @@ class _FusedLossFn(torch.autograd.Function):
         return ds, None, None, None, None, None
 
 
-def get_loss_fn(noise, graph, train=True, sampling_eps=1e-3, lv=False, fused=True):
+def get_loss_fn(noise, graph, train=True, sampling_eps=1e-3, lv=False, fused=True, conditioners=False):
+    """conditioners=False is the reference as written: loss_fn accepts esm_cond / mol_cond and drops them (the call that
+    would forward them is commented out, losses.py:26).  True forwards them to `SEDD.forward(indices, sigma, esm_cond,
+    mol_cond)` (transformer.py:277) — what that signature and the DDP trainer's call (run_train_ddp_protlig_transf.py:284)
+    are for."""
+
     def loss_fn(model, batch, cond=None, t=None, perturbed_batch=None, esm_cond=None, mol_cond=None, u=None):
         """Batch shape: [B, L] int64."""
         if t is None:
@@ -43,8 +48,12 @@ def get_loss_fn(noise, graph, train=True, sampling_eps=1e-3, lv=False, fused=Tru
         sigma, dsigma = noise(t)
         if perturbed_batch is None:
             perturbed_batch = graph.sample_transition(batch, sigma[:, None], u=u)
-        log_score_fn = mutils.get_score_fn(model, train=train, sampling=False)
-        log_score = log_score_fn(perturbed_batch, sigma)
+        if conditioners and (esm_cond is not None or mol_cond is not None):
+            model.train(train)
+            log_score = model(perturbed_batch, sigma.reshape(-1), esm_cond, mol_cond)
+        else:
+            log_score_fn = mutils.get_score_fn(model, train=train, sampling=False)
+            log_score = log_score_fn(perturbed_batch, sigma)
         if fused and log_score.requires_grad:
             return _FusedLossFn.apply(log_score, graph, sigma, dsigma, perturbed_batch, batch)
         loss = graph.score_entropy(log_score, sigma[:, None], perturbed_batch, batch)

@@ -286,10 +286,69 @@ class _SEDD(nn.Module):
         return _EpilogueFn.apply(x, sigma, indices, bool(self.scale_by_sigma))
 
 
+COND_PARAMS = ("proj.weight", "proj.bias", "norm.weight", "norm.bias")
+
+
+class _PooledCondFn(torch.autograd.Function):
+    """transformer.py:289-301: c' = mean([c, esm_norm(esm_proj(esm_cond)), mol_norm(mol_proj(mol_cond))]) over the terms
+    that are given.  The projections are fp32 Linears (they sit outside the reference's autocast region) on the MFMA
+    GEMM; both BatchNorm1d's (batch or running statistics, running-stat update) and the mean are one kernel."""
+
+    @staticmethod
+    def forward(ctx, c, esm_cond, mol_cond, model, save, *params):
+        terms, lin_in, mods = [], [], []
+        for k, (cond, proj, norm) in enumerate(((esm_cond, model.esm_proj, getattr(model, "esm_norm", None)),
+                                                (mol_cond, model.mol_proj, getattr(model, "mol_norm", None)))):
+            if cond is None or proj is None:
+                terms.append(None)
+                lin_in.append(None)
+                mods.append(None)
+                continue
+            xin = cond.detach().float().contiguous()
+            lin = Lyr.linear_fwd(xin, proj.weight, proj.bias)
+            terms.append((lin, norm.weight.detach(), norm.bias.detach(), norm.running_mean, norm.running_var))
+            lin_in.append(xin)
+            mods.append((proj, norm))
+        training = next((m[1].training for m in mods if m is not None), model.training)
+        momentum = 0.1
+        for m in mods:
+            if m is not None:
+                momentum = m[1].momentum if m[1].momentum is not None else 0.1
+        out, saved = ops.cond_combine_fwd(c.contiguous(), terms, training, momentum,
+                                          next((m[1].eps for m in mods if m is not None), 1e-5))
+        if training:
+            for m in mods:
+                if m is not None and m[1].num_batches_tracked is not None:
+                    m[1].num_batches_tracked.add_(1)
+        ctx.saved, ctx.lin_in, ctx.mods, ctx.training = (saved, lin_in, mods, training) if save else (None,) * 4
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, lin_in, mods, training = ctx.saved, ctx.lin_in, ctx.mods, ctx.training
+        weights = [None if m is None else m[1].weight.detach() for m in mods]
+        sinks = [None if m is None or m[1].weight.grad is None or m[1].bias.grad is None
+                 else (m[1].weight.grad, m[1].bias.grad) for m in mods]
+        if any(s is None for s, m in zip(sinks, mods) if m is not None):
+            sinks = [None, None]
+        dc, dxs, dws = ops.cond_combine_bwd(dout.contiguous(), saved, weights, sinks, training)
+        grads = []
+        for k, m in enumerate(mods):
+            if m is None:
+                grads += [None] * 4
+                continue
+            proj, norm = m
+            _, dW, db = Lyr.linear_bwd(lin_in[k], dxs[k], proj.weight, proj.bias, need_dx=False)
+            dnw, dnb = dws[k] if dws[k] is not None else (None, None)
+            grads += [dW, db, dnw, dnb]
+        ctx.saved = ctx.lin_in = None
+        return (dc, None, None, None, None) + tuple(grads)
+
+
 class SEDD(_SEDD):
-    """transformer.py:240-325: _SEDD plus the optional pooled ESM / MolFormer conditioners (esm_proj, mol_proj and
-    BatchNorm1d, averaged with the sigma embedding, :289-301).  Those act on [B, cond_dim] vectors only when
-    esm_cond / mol_cond are given (never in the checked-in trainers' hot loop) and stay plain torch modules."""
+    """transformer.py:240-325: _SEDD plus the pooled ESM / MolFormer conditioners (esm_proj, mol_proj and BatchNorm1d,
+    averaged with the sigma embedding, :289-301) — what run_train_ddp_protlig_transf.py:284 calls with esm_cond /
+    mol_cond.  State-dict keys as the reference: esm_proj.*, mol_proj.*, esm_norm.*, mol_norm.* (incl. running stats)."""
 
     def __init__(self, config, compute_dtype=torch.bfloat16):
         super().__init__(config, compute_dtype)
@@ -311,9 +370,13 @@ class SEDD(_SEDD):
 
     def _cond(self, sigma, esm_cond=None, mol_cond=None):
         c = self.sigma_map(sigma, silu=True)
-        conds = [c]
-        if self.esm_proj is not None and esm_cond is not None:
-            conds.append(self.esm_norm(self.esm_proj(esm_cond)))
-        if self.mol_proj is not None and mol_cond is not None:
-            conds.append(self.mol_norm(self.mol_proj(mol_cond)))
-        return c if len(conds) == 1 else torch.mean(torch.stack(conds), dim=0)
+        use_e = self.esm_proj is not None and esm_cond is not None
+        use_m = self.mol_proj is not None and mol_cond is not None
+        if not (use_e or use_m):
+            return c
+        params = []
+        for use, proj, norm in ((use_e, self.esm_proj, getattr(self, "esm_norm", None)),
+                                (use_m, self.mol_proj, getattr(self, "mol_norm", None))):
+            params += [proj.weight, proj.bias, norm.weight, norm.bias] if use else [None] * 4
+        return _PooledCondFn.apply(c, esm_cond if use_e else None, mol_cond if use_m else None, self,
+                                   torch.is_grad_enabled(), *params)

@@ -271,6 +271,64 @@ def timestep_embedding(sigma, dim=256):
     return out
 
 
+def cond_combine_fwd(c, terms, training, momentum=0.1, eps=1e-5):
+    """SEDD's pooled conditioners (transformer.py:289-301): mean([c, BN(x_e), BN(x_m)]).  terms: two entries (ESM,
+    MolFormer), each None or (x [B, C], weight, bias, running_mean, running_var); the running buffers are updated in
+    place in training mode.  -> (out [B, C], saved [(mean, rstd) or None] x 2)."""
+    _cuda(c)
+    c = _c(c, torch.float32)
+    B, C = c.shape
+    if training and B < 2 and any(t is not None for t in terms):  # torch's nn.BatchNorm1d error
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([B, C])}")
+    out = torch.empty_like(c)
+    args, saved, keep = [], [], []
+    for t in terms:
+        if t is None:
+            args += [None] * 7
+            saved.append(None)
+            continue
+        x, w, b, rm, rv = t
+        x = _c(x, torch.float32)
+        keep.append(x)
+        st = torch.empty(2, C, dtype=torch.float32, device=c.device)
+        saved.append((x, st[0], st[1]))
+        args += [_p(x), _p(w), _p(b), _p(rm), _p(rv), _p(st[0]), _p(st[1])]
+    check(lib().sedd_cond_combine_fwd(_p(c), *args, _p(out), 1 if training else 0, float(momentum), float(eps), B, C,
+                                      _stream()), "sedd_cond_combine_fwd")
+    return out, saved
+
+
+def cond_combine_bwd(dout, saved, weights, sinks, training, need_dx=(True, True)):
+    """-> (dc, [dx or None] x 2, [(dw, db) or None] x 2).  saved: from cond_combine_fwd; weights: BatchNorm weights;
+    sinks: per term (dw_buffer, db_buffer) to ACCUMULATE into, or None for fresh tensors (all terms alike)."""
+    dout = _c(dout, torch.float32)
+    B, C = dout.shape
+    dc = torch.empty_like(dout)
+    args, dxs, dws = [], [], []
+    accumulate = any(s is not None for s in sinks)
+    for sv, w, sink, ndx in zip(saved, weights, sinks, need_dx):
+        if sv is None:
+            args += [None] * 7
+            dxs.append(None)
+            dws.append(None)
+            continue
+        x, mean, rstd = sv
+        dx = torch.empty_like(x) if ndx else None
+        if sink is None:
+            z = torch.zeros(2, C, dtype=torch.float32, device=dout.device) if accumulate else \
+                torch.empty(2, C, dtype=torch.float32, device=dout.device)
+            dw, db = z[0], z[1]
+            dws.append((dw, db))
+        else:
+            dw, db = sink
+            dws.append(None)
+        dxs.append(dx)
+        args += [_p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db)]
+    check(lib().sedd_cond_combine_bwd(_p(dout), *args, _p(dc), 1 if training else 0, 1 if accumulate else 0, B, C,
+                                      _stream()), "sedd_cond_combine_bwd")
+    return dc, dxs, dws
+
+
 def silu_fwd(x):
     x = _c(x, torch.float32)
     y = torch.empty_like(x)

@@ -105,7 +105,7 @@ class SEDDTrainer:
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
-                 process_group=None, overlap=True, lr_schedule=None, ema=None):
+                 process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
@@ -136,7 +136,9 @@ class SEDDTrainer:
             for dst, src in zip(self.flat.ema_params(), ema.shadow_params):
                 dst.copy_(src)
         self.ema.shadow_params = self.flat.ema_params()
-        self.loss_fn = get_loss_fn(noise, graph, train=True, sampling_eps=sampling_eps)
+        # conditioners=True: train_step(..., esm_cond=, mol_cond=) reaches SEDD.forward's pooled conditioners (the
+        # reference's loss_fn drops them, losses.py:26 — default)
+        self.loss_fn = get_loss_fn(noise, graph, train=True, sampling_eps=sampling_eps, conditioners=conditioners)
         self.step_count = 0
         dev = self.flat.p.device
         self._ws = torch.empty(1024, dtype=torch.float32, device=dev)
@@ -186,7 +188,9 @@ class SEDDTrainer:
 
     def broadcast_parameters(self, src=0):
         dist.broadcast(self.flat.p, src, group=self.pg)
-        self.flat.ema.copy_(self.flat.p)
+        # the EMA shadow travels as its own buffer: on a fresh start it equals rank src's parameters anyway, on a resume
+        # (losses.get_step_fn adopting a restored state['ema']) it is the restored shadow and must survive the binding
+        dist.broadcast(self.flat.ema, src, group=self.pg)
         if self.flat.pc is not None:
             ops.cast(self.flat.p, torch.bfloat16, out=self.flat.pc)
         self.flat.refresh_compute_weights()
@@ -197,12 +201,13 @@ class SEDDTrainer:
             return float(sched(step))
         return self.lr * min(step / self.warmup, 1.0) if self.warmup and self.warmup > 0 else self.lr
 
-    def train_step(self, batch, t=None, perturbed_batch=None, u=None):
+    def train_step(self, batch, t=None, perturbed_batch=None, u=None, esm_cond=None, mol_cond=None):
         """One optimisation step (losses.py:80-115 with accum = 1). Returns the local loss (0-dim device tensor)."""
         fl = self.flat
         fl.g.zero_()
         self.model.train()
-        loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u)
+        loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
+                            mol_cond=mol_cond)
         loss.backward()
         self.apply_gradients()
         return loss.detach()

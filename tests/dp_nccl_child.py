@@ -68,6 +68,22 @@ def main(out_path):
                     "bit_identical": bool(same), "losses": got[0], "base_losses": base[0],
                     "max_abs_param_diff": float((got[1] - base[1]).abs().max())}
                 ok = ok and same
+        # resume through get_step_fn's adoption path: an EMA whose shadow differs from the weights survives the DP binding
+        from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
+        os.environ.update(SEDD_DP_FORCE="1", SEDD_DP_OVERLAP="0")
+        m2 = _SEDD(cfg, compute_dtype=torch.float32).to(dev)
+        ema2 = ExponentialMovingAverage(m2.parameters(), 0.9999)
+        with torch.no_grad():
+            for sp in ema2.shadow_params:
+                sp.add_(0.5)
+        ema2.num_updates = 77
+        tr2 = SEDDTrainer(m2, noise_lib.LogLinearNoise(eps=1e-3).to(dev), graph_lib.Absorbing(25), dict(lr=1e-3),
+                          world_size=1, ema=ema2)
+        torch.cuda.synchronize()
+        d = (tr2.flat.ema - tr2.flat.p)
+        live = torch.cat([tr2.flat.view(d, i).reshape(-1) for i in range(len(tr2.flat.params))])
+        res["ema_survives_binding"] = bool(tr2.dp and torch.allclose(live, torch.full_like(live, 0.5)) and ema2.num_updates == 77)
+        ok = ok and res["ema_survives_binding"]
         # gloo must be refused on device tensors (it hangs on this image; see train.init_distributed)
         dist.barrier()
         dist.destroy_process_group()

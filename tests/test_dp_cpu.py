@@ -44,6 +44,24 @@ def _worker(rank, world, port, q):
             assert p.data_ptr() == fl.view(fl.p, i).data_ptr() and p.grad.data_ptr() == fl.view(fl.g, i).data_ptr()
             assert fl.offsets[i] % 64 == 0
         assert torch.equal(fl.ema, fl.p)
+        # 1b. resume: an adopted EMA whose shadow differs from the weights survives the binding (rank 0's shadow wins)
+        from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
+        m2 = _SEDD(_cfg(), compute_dtype=torch.float32)
+        ema2 = ExponentialMovingAverage(m2.parameters(), 0.9999)
+        with torch.no_grad():
+            for sp in ema2.shadow_params:
+                sp.add_(1.0 + rank)
+        ema2.num_updates = 500
+        os.environ["SEDD_DP_OVERLAP"] = "0"
+        tr2 = SEDDTrainer(m2, noise_lib.LogLinearNoise(), graph_lib.Absorbing(25), dict(lr=1e-3), world_size=world, ema=ema2)
+        both = [torch.empty_like(tr2.flat.ema) for _ in range(world)]
+        dist.all_gather(both, tr2.flat.ema)
+        assert torch.equal(both[0], both[1])
+        i0 = next(i for i, p in enumerate(tr2.flat.params) if p.dim() == 2)
+        diff = tr2.flat.view(tr2.flat.ema, i0) - tr2.flat.view(tr2.flat.p, i0)
+        assert torch.allclose(diff, torch.ones_like(diff)), "restored EMA shadow was overwritten by the weights"
+        assert tr2.ema.num_updates == 500 and tr2.ema.shadow_params[i0].data_ptr() == tr2.flat.view(tr2.flat.ema, i0).data_ptr()
+        os.environ["SEDD_DP_OVERLAP"] = "1"
         # 2. buckets + leftovers tile [0, n) exactly once
         cover = sorted(tr._buckets + tr._leftover_ranges({(a, b) for a, b in tr._buckets}))
         pos = 0

@@ -9,7 +9,7 @@ import torch
 from conftest import assert_close, rel_err
 from oracle import sedd_cpu as O
 from oracle.weights import seeded_state_dict
-from test_oracle_vs_golden import _block_shapes, sedd_shapes
+from test_oracle_vs_golden import BN_BUFFERS, _block_shapes, sedd_cond_state, sedd_shapes
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -350,3 +350,86 @@ def test_g19_ddit_block_varlen(golden, tag):
         y16 = blk16(x, rot(x), c, seqlens=seqlens)
         ref16 = O.ddit_block(sd, "", g[t + "x"], g[t + "c"], H, bf16=True, seqlens=g[t + "seqlens"])
     assert rel_err(y16 - x.detach(), ref16.float() - g[t + "x"]) < 2e-2
+
+
+def _sedd_cond_model(cfgv, seed, dtype=torch.float32):
+    from protein_lig_sedd_amd.model.transformer import SEDD
+    D, H, C, nb, tokens, ed, md = cfgv
+    cfg = sedd_config(D, H, C, nb, tokens)
+    cfg.model.esm_dim, cfg.model.molformer_dim = ed, md
+    model = SEDD(cfg, compute_dtype=dtype).to(DEV)
+    sd = sedd_cond_state(D, H, C, nb, tokens + 1, ed, md, seed=seed)
+    missing, unexpected = model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("inv_freq") or k.endswith("num_batches_tracked") for k in missing), missing
+    return model, sd
+
+
+def test_g20_sedd_with_pooled_conditioners(golden):
+    """`SEDD.forward(indices, sigma, esm_cond, mol_cond)` (transformer.py:277-325) against the reference: eval and
+    training BatchNorm, the two- and three-term mean, running-statistic updates, loss and every gradient."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib, losses
+    g = golden("g20_sedd_conditioned")
+    model, _ = _sedd_cond_model(g["mini_cfg"].tolist(), seed=20)
+    tokens = int(g["mini_cfg"][4])
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    xt, x0, t = g["mini_xt"].to(DEV), g["mini_x0"].to(DEV), g["mini_t"].to(DEV)
+    sigma = noise(t)[0]
+    esm, mol = g["mini_esm"].to(DEV), g["mini_mol"].to(DEV)
+    model.eval()
+    with torch.no_grad():
+        for key, args in (("mini_eval_logits", (esm, mol)), ("mini_esm_eval_logits", (esm, None)),
+                          ("mini_none_eval_logits", (None, None))):
+            out = model(xt, sigma, *args)
+            assert rel_err(out, g[key]) < 1e-4, key
+            assert_close(out, g[key], 1e-4, 2e-4, key)
+    model.train()
+    loss = losses.get_loss_fn(noise, graph, train=True, conditioners=True)(model, x0, t=t, perturbed_batch=xt,
+                                                                           esm_cond=esm, mol_cond=mol)
+    assert_close(loss, g["mini_train_loss"], 1e-4, 0, "loss")
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = g["mini_train_grad." + k]
+        assert_close(p.grad, ref, 1e-4, max(1e-4 * float(ref.abs().max()), 1e-7), k)
+    for k in BN_BUFFERS:
+        mod, buf = k.split(".")
+        assert_close(getattr(getattr(model, mod), buf), g["mini_" + k + "1"], 1e-5, 1e-6, k)
+    assert int(model.esm_norm.num_batches_tracked) == 1 and int(model.mol_norm.num_batches_tracked) == 1
+    with torch.no_grad():
+        out = model(xt, sigma, esm, None)
+    assert_close(out, g["mini_esm_train_logits"], 1e-4, 2e-4, "esm-only training forward")
+    assert_close(model.esm_norm.running_mean, g["mini_esm_norm.running_mean2"], 1e-5, 1e-6)
+    assert_close(model.mol_norm.running_mean, g["mini_mol_norm.running_mean2"], 1e-5, 1e-6)
+    # as written, the reference's loss_fn DROPS the conditioners (losses.py:26): the default does the same
+    model.eval()
+    with torch.no_grad():
+        l0 = losses.get_loss_fn(noise, graph, train=False)(model, x0, t=t, perturbed_batch=xt, esm_cond=esm, mol_cond=mol)
+        l1 = losses.get_loss_fn(noise, graph, train=False)(model, x0, t=t, perturbed_batch=xt)
+    assert torch.equal(l0, l1)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        model.train()
+        model(xt[:1], sigma[:1], esm[:1], mol[:1])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_g20_config_large_dims(golden, dtype, tol):
+    """BASELINE configs[3] as configs/config_large.yaml writes it — D 1024, 16 heads, cond 128, tokens 2396 (V 2397),
+    L 1024, pooled conditioners 640 / 768 — against the reference (2 blocks): logits (row subsample + all row sums) and
+    the score-entropy loss over the full [2, 1024, 2397] log-score."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    g = golden("g20_sedd_conditioned")
+    model, _ = _sedd_cond_model(g["large_cfg"].tolist(), seed=24, dtype=dtype)
+    model.eval()
+    tokens = int(g["large_cfg"][4])
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    xt, x0, t = g["large_xt"].to(DEV), g["large_x0"].to(DEV), g["large_t"].to(DEV)
+    sigma, dsigma = noise(t)
+    with torch.no_grad():
+        logits = model(xt, sigma, g["large_esm"].to(DEV), g["large_mol"].to(DEV))
+        assert logits.dtype == dtype
+        rows = g["large_rows"].to(DEV)
+        assert rel_err(logits[:, rows].float(), g["large_logits_rows"]) < tol
+        assert rel_err(logits.double().sum(-1).float(), g["large_logits_rowsum"]) < tol
+        se = graph.score_entropy(logits, sigma[:, None], xt, x0)
+        assert rel_err(se, g["large_se"]) < tol
+        assert_close((dsigma[:, None] * se).mean(), g["large_loss"], tol, 0, "loss")

@@ -425,6 +425,76 @@ def test_g19_varlen_block(golden):
             assert_close(O.ddit_block({k: v.detach() for k, v in sd.items()}, "", g[t + "x"], g[t + "c"], H), g[t + "y_rows"], 1e-5, 1e-5)
 
 
+def sedd_cond_state(D, H, C, nb, V, esm_dim, mol_dim, seed):
+    """The g20 recipe (oracle/gen_golden.py::_load_sedd_cond): seeded weights by name, BatchNorm scales 1 + N(0, 0.02),
+    running statistics from a generator seeded seed + 7 (esm_norm first)."""
+    shapes = sedd_shapes(D, H, C, nb, V)
+    shapes.update({"esm_proj.weight": (C, esm_dim), "esm_proj.bias": (C,), "mol_proj.weight": (C, mol_dim),
+                   "mol_proj.bias": (C,), "esm_norm.weight": (C,), "esm_norm.bias": (C,), "mol_norm.weight": (C,),
+                   "mol_norm.bias": (C,)})
+    sd = seeded_state_dict(shapes, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 7)
+    for nm in ("esm_norm", "mol_norm"):
+        sd[nm + ".weight"] = sd[nm + ".weight"] + 1.0
+    for nm in ("esm_norm", "mol_norm"):
+        sd[nm + ".running_mean"] = torch.randn(C, generator=gen) * 0.05
+        sd[nm + ".running_var"] = 1.0 + 0.3 * torch.rand(C, generator=gen)
+    return sd
+
+
+BN_BUFFERS = ("esm_norm.running_mean", "esm_norm.running_var", "mol_norm.running_mean", "mol_norm.running_var")
+
+
+def test_g20_sedd_conditioned(golden):
+    """`SEDD.forward(indices, sigma, esm_cond, mol_cond)` (transformer.py:277-325): pooled-conditioner projections +
+    BatchNorm1d (train and eval statistics) + the mean over the given terms; and the config_large dims (V 2397, L 1024)."""
+    g = golden("g20_sedd_conditioned")
+    D, H, C, nb, tokens, ed, md = g["mini_cfg"].tolist()
+    sd = sedd_cond_state(D, H, C, nb, tokens + 1, ed, md, seed=20)
+    for k in BN_BUFFERS:
+        assert_close(sd[k], g["mini_" + k + "0"], 0, 0, k)
+    graph, noise = O.AbsorbingCPU(tokens), O.make_noise("loglinear", eps=1e-3)
+    xt, x0, sigma = g["mini_xt"], g["mini_x0"], g["mini_sigma"]
+    esm, mol = g["mini_esm"], g["mini_mol"]
+    with torch.no_grad():
+        assert_close(O.sedd_forward(sd, xt, sigma, H, nb, esm_cond=esm, mol_cond=mol), g["mini_eval_logits"], 1e-4, 1e-4)
+        assert_close(O.sedd_forward(sd, xt, sigma, H, nb, esm_cond=esm), g["mini_esm_eval_logits"], 1e-4, 1e-4)
+        assert_close(O.sedd_forward(sd, xt, sigma, H, nb), g["mini_none_eval_logits"], 1e-4, 1e-4)
+    assert float((g["mini_eval_logits"] - g["mini_none_eval_logits"]).abs().max()) > 1e-2   # the conditioners matter
+    sdg = {k: (v.clone().requires_grad_(True) if k not in BN_BUFFERS else v.clone()) for k, v in sd.items()}
+    logits = O.sedd_forward(sdg, xt, sigma, H, nb, esm_cond=esm, mol_cond=mol, training=True)
+    assert_close(logits, g["mini_train_logits"], 1e-4, 1e-4, "train logits")
+    dsigma = noise(g["mini_t"])[1]
+    loss = (dsigma[:, None] * graph.score_entropy(logits, sigma[:, None], xt, x0)).mean()
+    assert_close(loss, g["mini_train_loss"], 1e-5, 0)
+    loss.backward()
+    for k, v in sdg.items():
+        if k in BN_BUFFERS:
+            assert_close(v, g["mini_" + k + "1"], 1e-5, 1e-6, k)
+        else:
+            ref = g["mini_train_grad." + k]
+            # (a projection bias in front of a training-mode BatchNorm has an exactly-zero gradient: rounding noise only)
+            assert_close(v.grad, ref, 1e-3, max(1e-4 * float(ref.abs().max()), 1e-7), k)
+    assert int(g["mini_esm_norm.num_batches_tracked1"]) == 1
+    with torch.no_grad():
+        st = {k: v.detach().clone() for k, v in sdg.items()}
+        assert_close(O.sedd_forward(st, xt, sigma, H, nb, esm_cond=esm, training=True), g["mini_esm_train_logits"], 1e-4, 1e-4)
+        assert_close(st["esm_norm.running_mean"], g["mini_esm_norm.running_mean2"], 1e-5, 1e-6)
+        assert_close(st["mol_norm.running_mean"], g["mini_mol_norm.running_mean2"], 1e-5, 1e-6)   # untouched: == ...mean1
+        assert torch.equal(g["mini_mol_norm.running_mean2"], g["mini_mol_norm.running_mean1"])
+    # config_large dims
+    D, H, C, nb, tokens, ed, md = g["large_cfg"].tolist()
+    sd = sedd_cond_state(D, H, C, nb, tokens + 1, ed, md, seed=24)
+    graph = O.AbsorbingCPU(tokens)
+    with torch.no_grad():
+        logits = O.sedd_forward(sd, g["large_xt"], g["large_sigma"], H, nb, esm_cond=g["large_esm"], mol_cond=g["large_mol"])
+        assert_close(logits[:, g["large_rows"]], g["large_logits_rows"], 1e-4, 1e-4, "large logits")
+        assert_close(logits.double().sum(-1).float(), g["large_logits_rowsum"], 1e-4, 1e-2, "large row sums")
+        se = graph.score_entropy(logits, g["large_sigma"][:, None], g["large_xt"], g["large_x0"])
+        assert_close(se, g["large_se"], 1e-4, 1e-4, "large score entropy")
+        assert_close((noise(g["large_t"])[1][:, None] * se).mean(), g["large_loss"], 1e-5, 0)
+
+
 def test_philox4x32_10_known_answers():
     """The oracle's Philox4x32-10 against the Random123 known-answer vectors (kat_vectors: zero, all-ones and pi-digit
     counters / keys) — the generator sedd_predictor_step_philox runs in-kernel; and the uniform map's range."""
