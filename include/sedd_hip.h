@@ -7,7 +7,7 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees or synchronises
- *    (exception: none in this header), launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ *    (one exception: sedd_ln_modulate_bwd_noalloc works in a file-scope __device__ scratch of the library, see there), launches are asynchronous on `stream` (a hipStream_t passed as void*).
  *  - tensors are dense row-major unless strides are given; index tensors are int64 (torch.long) as in the
  *    reference; per-batch scalars (sigma, dsigma, ...) are fp32 arrays of length B; M = B*L rows, row r belongs
  *    to batch r / L.
@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SEDD_ABI_VERSION 4
+#define SEDD_ABI_VERSION 5
 
 typedef void* sedd_stream_t; /* hipStream_t */
 
@@ -35,7 +35,7 @@ enum sedd_graph { SEDD_ABSORB = 0, SEDD_UNIFORM = 1 };
 /* predictor step kinds: sampling/sampling.py:59-80 (Euler), :88-99 (Analytic), :102-132 (Denoiser) */
 enum sedd_step { SEDD_STEP_EULER = 0, SEDD_STEP_ANALYTIC = 1, SEDD_STEP_DENOISE = 2 };
 /* GEMM epilogues */
-enum sedd_epilogue { SEDD_EPI_NONE = 0, SEDD_EPI_BIAS = 1, SEDD_EPI_BIAS_GELU = 2 };
+enum sedd_epilogue { SEDD_EPI_NONE = 0, SEDD_EPI_BIAS = 1, SEDD_EPI_BIAS_GELU = 2, SEDD_EPI_BIAS_GELU_GRAD = 3 };
 
 int sedd_abi_version(void);
 const char* sedd_last_error(void);
@@ -247,7 +247,9 @@ int sedd_scale_(void* x, int dtype, const float* scale, int64_t n, sedd_stream_t
  * C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (GELU-tanh), both operands K-contiguous ("NT").
  * in_dtype: SEDD_BF16 (v_mfma_f32_16x16x32_bf16) or SEDD_F32 (exact-fp32 v_mfma_f32_32x32x2_f32);
  * fp32 accumulation; C in out_dtype; accumulate != 0: C += (fp32 C only; weight-gradient accumulation).
- * bias fp32 or NULL.  For SEDD_EPI_BIAS_GELU, pre (may be NULL) receives the pre-activation (out_dtype).
+ * bias fp32 or NULL.  For SEDD_EPI_BIAS_GELU, pre (may be NULL) receives the pre-activation (out_dtype); for
+ * SEDD_EPI_BIAS_GELU_GRAD it receives gelu_tanh'(pre-activation) instead (same sigmoid as the activation: what autograd's
+ * GELU backward multiplies by, handed to sedd_gemm_nn_dmul / sedd_gemm_nt_dmul).
  * Requirements: K % 8 == 0 (bf16) / K % 4 == 0 (fp32), lda/ldb multiples of the same, 16-byte aligned bases. */
 int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, const float* bias, int epilogue, void* pre, int accumulate, int64_t M, int64_t N,
@@ -272,6 +274,11 @@ int sedd_gemm_nt_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                        int out_dtype, const void* pre, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
+/* sedd_gemm_nt_dgelu with the derivative already evaluated: C = (A * B^T) .* mul[M,N] (mul = what sedd_gemm_nt's
+ * SEDD_EPI_BIAS_GELU_GRAD epilogue stored in the forward pass); colsum / colsum_ws and requirements as above. */
+int sedd_gemm_nt_dmul(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                      int out_dtype, const void* mul, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
+                      sedd_stream_t stream);
 /* The QKV projection with the rotary position embedding applied in the GEMM epilogue (transformer.py:165-171: attn_qkv,
  * rearrange 'b s (three h d) -> b s three h d', rotary.apply_rotary_pos_emb): C = packed qkv [M, 3*H*d] = A[M,K] *
  * B[N,K]^T (+ bias), then the NeoX rotation of sedd_rotary_qkv (conj = 0) on the q and k columns with position
@@ -300,6 +307,10 @@ int sedd_gemm_nn_ws(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                        int out_dtype, const void* pre, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
                        sedd_stream_t stream);
+/* sedd_gemm_nt_dmul with B given as [K, N]: C = (A[M,K] * B[K,N]) .* mul[M,N]; colsum += column sums of C. */
+int sedd_gemm_nn_dmul(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                      int out_dtype, const void* mul, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
+                      sedd_stream_t stream);
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
  * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SEDD_HIP_LIB") or os.path.join(_HERE, "libsedd_hip.so
 F32, BF16 = 0, 1
 ABSORB, UNIFORM = 0, 1
 STEP_EULER, STEP_ANALYTIC, STEP_DENOISE = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GELU_GRAD = 0, 1, 2, 3
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float}
 
@@ -62,6 +62,8 @@ SIGNATURES = {
     "sedd_gemm_nn_ws": "plplpliipilllplp",
     "sedd_gemm_nt_rotary": "plplpliipippiiilllp",
     "sedd_gemm_nn_dgelu": "plplpliippplllp",
+    "sedd_gemm_nt_dmul": "plplpliippplllp",
+    "sedd_gemm_nn_dmul": "plplpliippplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
     "sedd_attn_bwd": "ppppppp" + "pppp" + "iiiiii" + "llllll" + "ppp",
     "sedd_attn_varlen_fwd": "pppppp" + "iiiiii" + "lll" + "p",

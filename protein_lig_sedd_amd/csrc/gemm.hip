@@ -89,7 +89,27 @@ template <typename TO> __device__ __forceinline__ f32x4 gelu_grad4_t(f32x4 u) {
         return o;
     }
 }
-#define EPI_DGELU 3  // internal (sedd_gemm_nt_dgelu): C = (A B^T) * gelu_tanh'(pre), pre is an INPUT, column sums out
+// gelu_tanh and its derivative from ONE sigmoid (the forward's SEDD_EPI_BIAS_GELU_GRAD epilogue hands the derivative to
+// the backward, whose fused data-gradient epilogue is then one multiply: EPI_DMUL)
+template <typename TO> __device__ __forceinline__ void gelu_both4_t(f32x4 u, f32x4& g, f32x4& gp) {
+    if constexpr (sizeof(TO) == 2) {
+        const f32x4 u2 = u * u;
+        const f32x4 z = u * (-2.3022082f + -0.10294324f * u2);
+        f32x4 s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[r]));
+        const f32x4 w = u * (1.5957691216f + 0.21406445f * u2);
+        g = u * s;
+        gp = s + s * (w * (1.0f - s));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { g[r] = gelu_tanh_t<TO>(u[r]); gp[r] = gelu_tanh_grad_t<TO>(u[r]); }
+    }
+}
+// internal epilogues (sedd_gemm_nt_dgelu / _dmul): C = (A B^T) * gelu_tanh'(pre) resp. (A B^T) * pre; `pre` is an INPUT,
+// column sums out
+#define EPI_DGELU 16
+#define EPI_DMUL 17
 
 // bijective XCD-aware remap (8 XCDs): blocks that share an XCD get a contiguous range of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -128,7 +148,9 @@ template <> __device__ __forceinline__ void store_row4<bf16_t>(bf16_t* p, f32x4 
 }
 
 // epilogue for 4 consecutive columns [col, col+4) of one C row held in one accumulator
-template <typename TO>
+// GGM = false: instantiations that never see SEDD_EPI_BIAS_GELU_GRAD (the register-bound big-tile kernels, which have a
+// kernel variant of their own for it) do not carry its code
+template <typename TO, bool GGM = true>
 __device__ __forceinline__ void epilogue4(TO* __restrict__ C, int64_t ldc, TO* __restrict__ pre,
                                           const float* __restrict__ bias, int epi, int accumulate, int atomic,
                                           int64_t row, int64_t col, int64_t M, int64_t N, f32x4 v, bool vec_ok) {
@@ -139,17 +161,19 @@ __device__ __forceinline__ void epilogue4(TO* __restrict__ C, int64_t ldc, TO* _
         for (int r = 0; r < 4; ++r) v[r] += (col + r < N) ? bias[col + r] : 0.f;
     }
     TO* p = C + row * ldc + col;
-    if (epi == SEDD_EPI_BIAS_GELU) {
+    if (epi == SEDD_EPI_BIAS_GELU || (GGM && epi == SEDD_EPI_BIAS_GELU_GRAD)) {
         // the reference rounds the Linear output to the activation dtype before GELU
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = to_f32<TO>(from_f32<TO>(v[r]));
+        f32x4 keep = v;  // what `pre` receives: the pre-activation, or (GELU_GRAD) gelu'(pre-activation)
+        if (GGM && epi == SEDD_EPI_BIAS_GELU_GRAD) gelu_both4_t<TO>(v, v, keep);
+        else v = gelu4_t<TO>(v);
         if (pre) {
             TO* pp = pre + row * ldc + col;
-            if (full) store_row4<TO>(pp, v);
+            if (full) store_row4<TO>(pp, keep);
             else
-                for (int r = 0; r < 4 && col + r < N; ++r) pp[r] = from_f32<TO>(v[r]);
+                for (int r = 0; r < 4 && col + r < N; ++r) pp[r] = from_f32<TO>(keep[r]);
         }
-        v = gelu4_t<TO>(v);
     }
     if (accumulate) {
         if constexpr (sizeof(TO) == 4) {
@@ -436,7 +460,10 @@ extern "C" int sedd_debug_gemm_phase(uint64_t* host_dst) {
 #else
 #define PHASE_STAMP(k) do {} while (0)
 #endif
-template <typename TO, int BN_, int NST, bool TN, bool DG, int NW = 8, bool NNB = false, bool ROT = false>
+// DG: 0 = forward epilogues, 1 = EPI_DGELU (pre-activation in, gelu' computed here), 2 = EPI_DMUL (multiplier in),
+//     3 = forward with SEDD_EPI_BIAS_GELU_GRAD (a kernel of its own: the 256-wide tiles sit at the register limit and a
+//     run-time choice between the two GELU epilogues spilled in every instantiation)
+template <typename TO, int BN_, int NST, bool TN, int DG, int NW = 8, bool NNB = false, bool ROT = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
@@ -692,7 +719,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                             make_float4(old[n].x + acc[m][n][0], old[n].y + acc[m][n][1], old[n].z + acc[m][n][2],
                                         old[n].w + acc[m][n][3]);
                     else
-                        epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, 0, row, col, M, N, acc[m][n], vec_ok);
+                        epilogue4<TO, DG == 3>(C, ldc, pre, bias, epi, accumulate, 0, row, col, M, N, acc[m][n], vec_ok);
                 }
             }
         } else if (!staged) {  // fp32 / split-K atomics / accumulate / unaligned C: straight from the accumulators
@@ -700,7 +727,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
             for (int m = 0; m < TM; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    epilogue4<TO>(C, ldc, pre, bias, epi, accumulate, splitk > 1, row_t + m * 16 + (lane & 15),
+                    epilogue4<TO, DG == 3>(C, ldc, pre, bias, epi, accumulate, splitk > 1, row_t + m * 16 + (lane & 15),
                                   col_w + n * 16 + 4 * (lane >> 4), M, N, acc[m][n], vec_ok);
         } else if constexpr (STAGED) {
             using SC = StageCfg<TO>;
@@ -710,7 +737,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 bv[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (epi == SEDD_EPI_BIAS || epi == SEDD_EPI_BIAS_GELU) {
+                if (epi == SEDD_EPI_BIAS || epi == SEDD_EPI_BIAS_GELU || DG == 3) {
                     const int64_t c = col_w + n * 16 + 4 * (lane >> 4);
                     bv[n].x = c + 0 < N ? bias[c + 0] : 0.f;
                     bv[n].y = c + 1 < N ? bias[c + 1] : 0.f;
@@ -718,14 +745,54 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                     bv[n].w = c + 3 < N ? bias[c + 3] : 0.f;
                 }
             }
-            if constexpr (DG) {
+            if constexpr (DG == 1 || DG == 2) {
                 // data gradient through GELU: the pre-activation tile comes in with coalesced 16-byte loads (all
                 // passes up front, under the next tile's prologue), is re-read from the staging region in the MFMA
                 // layout, and the column sums of the result (the bias gradient of the Linear below) are reduced over
                 // the wave's rows and added to colsum with one atomic per column and wave
+                f32x4 cs[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) cs[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (DG == 2) {
+                    // multiplier tile straight from global memory in the accumulator layout (lane: row lane & 15, the 4
+                    // columns of fragment n): 8-byte loads, the four fragments of a row together cover its 128-byte line;
+                    // no LDS round trip and no sigmoid — the pass is a multiply, the column sums and the store
+                    constexpr int PD = TM;  // every pass in flight at once: the fragment registers are free here
+                    uint2 mv[PD][4];
+#define DMUL_LOAD(pass_)                                                                                             \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                                  \
+        const int64_t gr = row_t + (pass_) * 16 + (lane & 15), gc = col_w + n * 16 + 4 * (lane >> 4);                \
+        mv[(pass_) % PD][n] = make_uint2(0, 0);                                                                      \
+        if (gr < M && gc + 4 <= N) mv[(pass_) % PD][n] = *reinterpret_cast<const uint2*>(pre + gr * ldc + gc);       \
+    }
+#pragma unroll
+                    for (int pass = 0; pass < PD; ++pass) DMUL_LOAD(pass)
+#pragma unroll
+                    for (int pass = 0; pass < TM; ++pass) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            union { uint2 u; TO e[4]; } pv;
+                            pv.u = mv[pass % PD][n];
+                            f32x4& v = acc[pass][n];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                // the reference rounds the Linear's data gradient to the activation dtype before GELU's
+                                const float dy = to_f32<TO>(from_f32<TO>(v[r]));
+                                v[r] = to_f32<TO>(from_f32<TO>(dy * to_f32<TO>(pv.e[r])));
+                                cs[n][r] += v[r];  // (rows / columns beyond the matrix: multiplier 0, so they add 0)
+                            }
+                        }
+                        if (pass + PD < TM) DMUL_LOAD(pass + PD)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+                            stage_put4<TO>(reg, lane & 15, n * 16 + 4 * (lane >> 4), acc[pass][n]);
+                        stage_flush<TO>(reg, C, ldc, row_t + pass * 16, col_w, M, N, lane, 0);
+                    }
+#undef DMUL_LOAD
+                } else {
                 constexpr int RPI = 64 / SC::LPR;
                 const int rsub = lane / SC::LPR, chunk = lane % SC::LPR;
-                constexpr int PD = TM > 4 ? 2 : 4;  // passes of pre-activation kept in flight (register budget)
+                constexpr int PD = TM > 4 ? 2 : 4;  // passes of `pre` kept in flight (register budget)
                 uint4 pr[PD][SC::RPP / RPI];
 #define DGELU_LOAD(pass_)                                                                                            \
     _Pragma("unroll") for (int i = 0; i < SC::RPP / RPI; ++i) {                                                      \
@@ -735,9 +802,6 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     }
 #pragma unroll
                 for (int pass = 0; pass < PD; ++pass) DGELU_LOAD(pass)
-                f32x4 cs[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) cs[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pass = 0; pass < TM; ++pass) {
 #pragma unroll
@@ -766,6 +830,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                     stage_flush<TO>(reg, C, ldc, row_t + pass * 16, col_w, M, N, lane, 0);
                 }
 #undef DGELU_LOAD
+                }
                 if (colsum) {
                     // the block's WM row groups meet in LDS (each wave's staging region is free after its last flush)
                     // and leave with ONE atomic per column and block, added in a fixed order: with a single row tile
@@ -821,8 +886,9 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
 #pragma unroll
             for (int pass = 0; pass < TM / FPP; ++pass) {
                 const int64_t row_w = row_t + pass * SC::RPP;
-                if (epi == SEDD_EPI_BIAS_GELU) {
-                    // the reference rounds the Linear output to the activation dtype before GELU; `pre` keeps it
+                if (DG == 3 || epi == SEDD_EPI_BIAS_GELU) {
+                    // the reference rounds the Linear output to the activation dtype before GELU; `pre` keeps it (or,
+                    // GELU_GRAD, the derivative there: both come out of the one sigmoid)
 #pragma unroll
                     for (int mm = 0; mm < FPP; ++mm)
 #pragma unroll
@@ -832,8 +898,14 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                             v[1] = to_f32<TO>(from_f32<TO>(v[1] + bv[n].y));
                             v[2] = to_f32<TO>(from_f32<TO>(v[2] + bv[n].z));
                             v[3] = to_f32<TO>(from_f32<TO>(v[3] + bv[n].w));
-                            if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), v);
-                            v = gelu4_t<TO>(v);
+                            if constexpr (DG == 3) {
+                                f32x4 gp;
+                                gelu_both4_t<TO>(v, v, gp);
+                                if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), gp);
+                            } else {
+                                if (pre) stage_put4<TO>(reg, mm * 16 + (lane & 15), n * 16 + 4 * (lane >> 4), v);
+                                v = gelu4_t<TO>(v);
+                            }
                         }
                     if (pre) stage_flush<TO>(reg, pre, ldc, row_w, col_w, M, N, lane, 0);
                 } else if (epi == SEDD_EPI_BIAS) {
@@ -958,9 +1030,9 @@ __device__ __forceinline__ void epilogue1(TO* __restrict__ C, int64_t ldc, TO* _
                                           int64_t col, int64_t M, int64_t N, float v) {
     if (row >= M || col >= N) return;
     if (epi != SEDD_EPI_NONE) v += bias[col];
-    if (epi == SEDD_EPI_BIAS_GELU) {
+    if (epi == SEDD_EPI_BIAS_GELU || epi == SEDD_EPI_BIAS_GELU_GRAD) {
         const TO r = from_f32<TO>(v);
-        if (pre) pre[row * ldc + col] = r;
+        if (pre) pre[row * ldc + col] = epi == SEDD_EPI_BIAS_GELU_GRAD ? from_f32<TO>(gelu_tanh_grad_f(to_f32<TO>(r))) : r;
         v = gelu_tanh_f(to_f32<TO>(r));
     }
     TO* p = C + row * ldc + col;
@@ -1262,9 +1334,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             return SEDD_ERR_UNSUPPORTED_SHAPE;
         }
     }
-    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= EPI_DGELU, "gemm_nt: bad epilogue %d", epilogue);
+    const bool dg = epilogue == EPI_DGELU || epilogue == EPI_DMUL;
+    SEDD_CHECK_ARG((epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU_GRAD) || dg, "gemm_nt: bad epilogue %d", epilogue);
     SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_nt: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || epilogue == EPI_DGELU || bias, "gemm_nt: epilogue needs a bias");
+    SEDD_CHECK_ARG(epilogue == SEDD_EPI_NONE || dg || bias, "gemm_nt: epilogue needs a bias");
     SEDD_CHECK_ARG(!accumulate || epilogue == SEDD_EPI_NONE, "gemm_nt: accumulate only with SEDD_EPI_NONE");
     const int kal = in_dtype == SEDD_BF16 ? 8 : 4;
     if (K % kal || lda % kal || ldb % kal || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || lda < K || (!b_kn && ldb < K) ||
@@ -1282,7 +1355,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if (in_dtype == SEDD_BF16) {
         // big-tile path: 256 x 256 or 256 x 128 tiles, whichever quantises better onto the 256 CUs
         const bool big_ok = K % BIG_BK == 0 && M >= 192 && N >= 96 && (b_kn || !getenv("SEDD_GEMM_SMALL_TILES"));
-        if (epilogue == EPI_DGELU) {
+        if (dg) {
             // only the big-tile kernel's staged bf16 epilogue implements it
             if (!big_ok || out_dtype != SEDD_BF16 || accumulate || (ldc * 2) % 16 || ((uintptr_t)C & 15) ||
                 ((uintptr_t)pre & 15) || N % 8) {
@@ -1313,39 +1386,39 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
             if (splitk == 1) tn |= (int64_t)choose_csplit(tm, tn, tiles, M, N, K) << 20;  // (tn is only passed on from here)
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, 0>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, bias, epilogue, (TO*)pre, accumulate, M, N, kper, K,      \
                        (int)tn, (int)tiles, splitk, (float4*)nullptr, colsum, kNoRot)
 #define BIG_LAUNCH_X(BN_, DG_, NNB_)                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, BN_, 4, false, DG_, 8, NNB_>), g2, dim3(512), 0, st,            \
                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre,   \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, (float4*)(DG_ ? colsum_ws : nullptr),   \
-                       colsum, kNoRot)
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,                                        \
+                       (float4*)(DG_ == 1 || DG_ == 2 ? colsum_ws : nullptr), colsum, kNoRot)
             if (rot) {
-                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, false, 8, false, true>), g2, dim3(512), 0,
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, 0, 8, false, true>), g2, dim3(512), 0,
                                        st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
                                        (float4*)nullptr, colsum, *rot);
+            } else if (dg) {
+                const int dgk = epilogue == EPI_DMUL ? 2 : 1;
+                if (b_kn) {
+                    if (dgk == 2) { if (wide) BIG_LAUNCH_X(256, 2, true); else BIG_LAUNCH_X(128, 2, true); }
+                    else { if (wide) BIG_LAUNCH_X(256, 1, true); else BIG_LAUNCH_X(128, 1, true); }
+                } else {
+                    if (dgk == 2) { if (wide) BIG_LAUNCH_X(256, 2, false); else BIG_LAUNCH_X(128, 2, false); }
+                    else { if (wide) BIG_LAUNCH_X(256, 1, false); else BIG_LAUNCH_X(128, 1, false); }
+                }
             } else if (b_kn) {
-                if (epilogue == EPI_DGELU) { if (wide) BIG_LAUNCH_X(256, true, true); else BIG_LAUNCH_X(128, true, true); }
-                else { if (wide) BIG_LAUNCH_X(256, false, true); else BIG_LAUNCH_X(128, false, true); }
-            } else if (epilogue == EPI_DGELU && wide) {
-                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 256, 4, false, true>), g2, dim3(512), 0, st,
-                                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
-                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)colsum_ws, colsum, kNoRot);
-            } else if (epilogue == EPI_DGELU) {
-                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, true>), g2, dim3(512), 0, st,
-                                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
-                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
-                                       (float4*)colsum_ws, colsum, kNoRot);
+                if (wide) BIG_LAUNCH_X(256, 0, true); else BIG_LAUNCH_X(128, 0, true);
+            } else if (out_dtype == SEDD_BF16 && epilogue == SEDD_EPI_BIAS_GELU_GRAD) {
+                if (wide) BIG_LAUNCH_X(256, 3, false); else BIG_LAUNCH_X(128, 3, false);
             } else if (out_dtype == SEDD_BF16) {
                 static const int nw4 = getenv("SEDD_GEMM_NW4") ? atoi(getenv("SEDD_GEMM_NW4")) : 0;
                 if (nw4 && splitk == 1 && (nw4 == 2 || !wide)) {
                     // two 256-thread blocks per CU, 256 x 128 tiles
                     const int64_t tn4 = (N + 127) / 128, tiles4 = tm * tn4;
                     const dim3 g4((unsigned)(tiles4 < 512 ? tiles4 : 512));
-                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 3, false, false, 4>), g4, dim3(256), 0, st,
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 3, false, 0, 4>), g4, dim3(256), 0, st,
                                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn4, (int)tiles4, 1,
                                        (float4*)nullptr, colsum, kNoRot);
@@ -1357,7 +1430,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             }
 #undef BIG_LAUNCH
 #undef BIG_LAUNCH_X
-            if (epilogue == EPI_DGELU && colsum && colsum_ws) {
+            if (dg && colsum && colsum_ws) {
                 SEDD_LAUNCH_CHECK();
                 hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, colsum_ws,
                                    (int)tm, N, colsum);
@@ -1406,7 +1479,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
 extern "C" int sedd_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                             int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
                             int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
-    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU, "gemm_nt: bad epilogue %d", epilogue);
+    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU_GRAD, "gemm_nt: bad epilogue %d", epilogue);
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, pre, accumulate, M, N, K, nullptr,
                         stream);
 }
@@ -1417,7 +1490,7 @@ extern "C" int sedd_gemm_nt_ws(const void* A, int64_t lda, const void* B, int64_
                                int in_dtype, int out_dtype, const float* bias, int epilogue, void* pre, int accumulate,
                                int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
                                sedd_stream_t stream) {
-    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU, "gemm_nt_ws: bad epilogue %d", epilogue);
+    SEDD_CHECK_ARG(epilogue >= SEDD_EPI_NONE && epilogue <= SEDD_EPI_BIAS_GELU_GRAD, "gemm_nt_ws: bad epilogue %d", epilogue);
     SEDD_CHECK_ARG(workspace_bytes >= 0 && (!workspace || ((uintptr_t)workspace & 15) == 0), "gemm_nt_ws: bad workspace");
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, bias, epilogue, pre, accumulate, M, N, K, nullptr,
                         stream, false, nullptr, nullptr, (float*)workspace, workspace_bytes);
@@ -1430,6 +1503,17 @@ extern "C" int sedd_gemm_nt_dgelu(const void* A, int64_t lda, const void* B, int
                                   int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
     SEDD_CHECK_ARG(pre, "gemm_nt_dgelu: pre is null");
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DGELU, const_cast<void*>(pre), 0, M, N,
+                        K, colsum, stream, false, nullptr, colsum_ws);
+}
+
+// C[M,N] = (A[M,K] * B[N,K]^T) .* mul[M,N]; colsum[N] += column sums of C (optional): sedd_gemm_nt_dgelu with the
+// derivative already evaluated by the forward pass (sedd_gemm_nt's SEDD_EPI_BIAS_GELU_GRAD writes gelu'(pre-activation)
+// where SEDD_EPI_BIAS_GELU writes the pre-activation) — the epilogue is a multiply instead of a sigmoid per element.
+extern "C" int sedd_gemm_nt_dmul(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                 int in_dtype, int out_dtype, const void* mul, float* colsum, float* colsum_ws,
+                                 int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(mul, "gemm_nt_dmul: mul is null");
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DMUL, const_cast<void*>(mul), 0, M, N,
                         K, colsum, stream, false, nullptr, colsum_ws);
 }
 
@@ -1505,6 +1589,15 @@ extern "C" int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int
                         K, colsum, stream, true, nullptr, colsum_ws);
 }
 
+// sedd_gemm_nt_dmul with B given as [K, N]
+extern "C" int sedd_gemm_nn_dmul(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                 int in_dtype, int out_dtype, const void* mul, float* colsum, float* colsum_ws,
+                                 int64_t M, int64_t N, int64_t K, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(mul, "gemm_nn_dmul: mul is null");
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, nullptr, EPI_DMUL, const_cast<void*>(mul), 0, M, N,
+                        K, colsum, stream, true, nullptr, colsum_ws);
+}
+
 // C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations
 // (dW[out,in] = dY[tokens,out]^T X[tokens,in]), no transposed copies.  bf16 operands, fp32 or bf16 C.
 extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
@@ -1559,7 +1652,7 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     }
     const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
 #define TN_LAUNCH(TO, BN_)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, false>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, 0>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \
                        accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, (float*)nullptr, kNoRot)
     if (out_dtype == SEDD_BF16) {

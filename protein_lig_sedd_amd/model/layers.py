@@ -109,10 +109,20 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
     return dx, dW, db
 
 
-def mlp_out_bwd(g2d, u2d, dy2d, W2, b2, b1):
+def mlp_out_bwd(g2d, u2d, dy2d, W2, b2, b1, u_is_grad=False):
     """backward of `y = Linear2(GELU(u))` down to du: -> (du, dW2, db2, db1).  The data gradient, GELU's derivative and
-    the first Linear's bias gradient (column sums of du) are one GEMM launch when the shapes allow."""
+    the first Linear's bias gradient (column sums of du) are one GEMM launch when the shapes allow.  u_is_grad: `u2d`
+    holds gelu'(u) (the forward's GELU_GRAD epilogue) and the launch's epilogue is one multiply."""
     W2c = compute_weight(W2, dy2d.dtype)
+    if u_is_grad:
+        if not (ops.gemm_nn_supported(dy2d, W2c) and u2d.is_contiguous() and u2d.data_ptr() % 16 == 0):
+            raise RuntimeError("mlp_out_bwd: the forward stored gelu' for a shape the fused data gradient cannot take")
+        _, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2, need_dx=False)
+        bs = _sink(b1)
+        db1 = None
+        if bs is None:
+            bs = db1 = torch.zeros(u2d.shape[1], dtype=torch.float32, device=u2d.device)
+        return ops.gemm_dmul(dy2d, W2c, u2d, colsum=bs), dW2, db2, db1
     if (ops.gemm_nn_supported(dy2d, W2c) and u2d.dtype == torch.bfloat16 and u2d.is_contiguous()
             and u2d.data_ptr() % 16 == 0 and not os.environ.get("SEDD_NO_DGELU")):
         _, dW2, db2 = linear_bwd(g2d, dy2d, W2, b2, need_dx=False)
@@ -193,8 +203,12 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
     else:
         x1 = ops.gate_residual_fwd(x, a, mod[:, 2 * D:3 * D], keep1, inv)
         h2, mean2, rstd2 = ops.ln_modulate_fwd(x1, w2, shift=mod[:, 3 * D:4 * D], scale=mod[:, 4 * D:5 * D], out_dtype=cdt)
+    W1 = P["mlp.0.weight"]
+    # the backward's fused data gradient through GELU multiplies by gelu'(u): when it will run (static shape test) the
+    # forward stores that derivative — from the sigmoid it evaluates anyway — in place of u
+    u_grad = save and ops.gemm_dmul_shapes_ok(M, W1.shape[0], D, cdt) and P["mlp.2.weight"].stride(0) % 8 == 0
     if save:
-        g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True, want_pre=True)
+        g, u = linear_fwd(h2.view(M, D), W1, P["mlp.0.bias"], gelu=True, want_pre="grad" if u_grad else True)
     else:
         g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True), None
     y = linear_fwd(g, P["mlp.2.weight"], P["mlp.2.bias"]).view(B, L, D)
@@ -203,8 +217,8 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
     st = None
     if save:
         st = dict(x=x, c=c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
-                  x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, g=g, y=y, keep2=keep2, inv=inv, cos=cos, sin=sin,
-                  cu=cu_seqlens)
+                  x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, u_grad=u_grad, g=g, y=y, keep2=keep2, inv=inv, cos=cos,
+                  sin=sin, cu=cu_seqlens)
     return x2, st
 
 
@@ -222,7 +236,7 @@ def ddit_block_backward(dx2, st, P, n_heads):
     dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"],
                                dbias=db2).view(M, D)
     du, grads["mlp.2.weight"], _, grads["mlp.0.bias"] = mlp_out_bwd(
-        st["g"], st["u"], dy, P["mlp.2.weight"], None, P["mlp.0.bias"])
+        st["g"], st["u"], dy, P["mlp.2.weight"], None, P["mlp.0.bias"], u_is_grad=st["u_grad"])
     dh2, grads["mlp.0.weight"], _ = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], None)
     dw2, grads["norm2.weight"] = _vec_sink(P["norm2.weight"], D)
     # ---- attention branch: x1 = x + gate_msa * dropout(attn_out(attn(rotary(qkv(modulate(LN(x)))))))

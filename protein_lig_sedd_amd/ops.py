@@ -594,7 +594,8 @@ def cast(a, dtype, out=None):
 # ------------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=False, want_pre=False):
     """C[M,N] = A[M,K] @ B[N,K]^T (+bias)(GELU). A, B share dtype (bf16 or fp32), row strides allowed.
-    -> C, or (C, pre) when gelu and want_pre."""
+    -> C, or (C, pre) when gelu and want_pre; want_pre="grad": `pre` holds gelu'(pre-activation) instead of the
+    pre-activation (for gemm_nn_dmul / gemm_nt_dmul)."""
     M, K = A.shape
     N, K2 = B.shape
     if K != K2 or A.dtype != B.dtype:
@@ -604,6 +605,8 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype or A.dtype, device=A.device)
     epi = _L.EPI_NONE if bias is None else (_L.EPI_BIAS_GELU if gelu else _L.EPI_BIAS)
+    if gelu and want_pre == "grad":
+        epi = _L.EPI_BIAS_GELU_GRAD
     if gelu and bias is None:
         raise ValueError("gemm_nt: GELU epilogue needs a bias")
     pre = torch.empty_like(out) if (gelu and want_pre) else None
@@ -661,6 +664,27 @@ def gemm_nt_dgelu(A, B, pre, colsum=None):
         check(lib().sedd_gemm_nt_dgelu(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                        _p(pre), _p(colsum), _p(_colsum_ws(A, M, N, colsum)), M, N, K, _stream()),
               "sedd_gemm_nt_dgelu")
+    return out
+
+
+def gemm_dmul_shapes_ok(M, N, K, dtype):
+    """whether the fused `dU = (dY W2) * gelu'` launch (sedd_gemm_nn_dmul / _nt_dmul) will take an [M, K] x [K, N] product
+    of freshly allocated bf16 tensors — decided in the forward pass, which then stores gelu' instead of the pre-activation."""
+    return (dtype == torch.bfloat16 and M >= 192 and N >= 96 and N % 8 == 0 and K % 32 == 0
+            and not os.environ.get("SEDD_NO_DGELU") and not os.environ.get("SEDD_NO_DMUL"))
+
+
+def gemm_dmul(A, B, mul, colsum=None, b_kn=True):
+    """C = (A[M,K] @ B) * mul[M,N] (bf16), B [K, N] (b_kn) or [N, K]; colsum fp32 [N] += C.sum(0) when given."""
+    M, K = A.shape
+    N = B.shape[1] if b_kn else B.shape[0]
+    if mul.shape != (M, N) or (B.shape[0] if b_kn else B.shape[1]) != K:
+        raise ValueError(f"gemm_dmul: A {tuple(A.shape)} B {tuple(B.shape)} mul {tuple(mul.shape)}")
+    out = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    fn = lib().sedd_gemm_nn_dmul if b_kn else lib().sedd_gemm_nt_dmul
+    with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+        check(fn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out), _p(mul), _p(colsum),
+                 _p(_colsum_ws(A, M, N, colsum)), M, N, K, _stream()), "sedd_gemm_dmul")
     return out
 
 

@@ -183,6 +183,45 @@ def test_gemm_nn_dgelu(M, N, K):
     assert rel_err(cs, cs2) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 3072, 768), (1000, 384, 96), (320, 1000, 64), (200, 136, 72), (16, 128, 64)])
+def test_gemm_gelu_grad_epilogue_and_dmul(M, N, K):
+    """forward epilogue that stores gelu'(pre) next to gelu(pre) (SEDD_EPI_BIAS_GELU_GRAD, every kernel family: big-tile
+    staged, small-tile, generic-K) and the backward's multiply epilogue (sedd_gemm_nn_dmul / _nt_dmul): the pair must
+    reproduce Linear -> GELU(tanh)'s autograd (transformer.py:129-133) like the pre-activation / dGELU pair does."""
+    ops = _ops()
+    torch.manual_seed(M + N + K + 2)
+    X = (0.5 * torch.randn(M, K, device=DEV)).bfloat16()
+    W1 = (0.3 * torch.randn(N, K, device=DEV)).bfloat16()
+    b1 = torch.randn(N, device=DEV)
+    g0, u = ops.gemm_nt(X, W1, bias=b1, gelu=True, want_pre=True)
+    g1, gp = ops.gemm_nt(X, W1, bias=b1, gelu=True, want_pre="grad")
+    assert torch.equal(g0, g1)
+    uf = u.float().requires_grad_(True)
+    F.gelu(uf, approximate="tanh").sum().backward()
+    assert rel_err(gp.float(), uf.grad) < 4e-3          # bf16 rounding of the stored derivative
+    assert float((gp.float() - uf.grad).abs().max()) < 1e-2
+    # fp32 operands: exact tanh forms
+    g32, gp32 = ops.gemm_nt(X.float(), W1.float(), bias=b1, gelu=True, want_pre="grad")
+    u32 = (X.float().double() @ W1.float().double().T + b1.double()).float().requires_grad_(True)
+    F.gelu(u32, approximate="tanh").sum().backward()
+    assert rel_err(gp32, u32.grad) < 1e-5 and rel_err(g32, F.gelu(u32.detach(), approximate="tanh")) < 1e-5
+    if not ops.gemm_dmul_shapes_ok(M, N, 64, torch.bfloat16):
+        return
+    Ko = 96
+    dY = (0.3 * torch.randn(M, Ko, device=DEV)).bfloat16()
+    W2 = (0.3 * torch.randn(Ko, N, device=DEV)).bfloat16()   # second Linear's weight as stored [out, hidden]
+    cs, cs_ref = torch.ones(N, device=DEV), torch.ones(N, device=DEV)
+    du = ops.gemm_dmul(dY, W2, gp, colsum=cs)
+    ref = ops.gemm_nn_dgelu(dY, W2, u, colsum=cs_ref)
+    assert rel_err(du.float(), ref.float()) < 6e-3       # one more bf16 rounding (the stored derivative) than the reference
+    assert rel_err(cs, cs_ref) < 5e-3
+    exact = (dY.double() @ W2.double()).float() * uf.grad
+    assert rel_err(du.float(), exact) < 1e-2
+    assert rel_err(cs - 1, du.float().sum(0)) < 1e-4     # the column sums are those of the stored result
+    du_nt = ops.gemm_dmul(dY, W2.t().contiguous(), gp, b_kn=False)
+    assert rel_err(du_nt.float(), du.float()) < 2e-3
+
+
 def test_gemm_nn_rejects_unsupported():
     ops = _ops()
     from protein_lig_sedd_amd._lib import SeddError
