@@ -1001,6 +1001,61 @@ def g20_sedd_conditioned():
     save("g20_sedd_conditioned", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G21
+def g21_plinder_collate():
+    """the reference's PLINDER list dataset + collate (data/process_full_plinder.py:31-243) and the seeded
+    split / DistributedSampler shards of its loaders (:293-301, :396-398) on a SYNTHETIC sample list (strings of random
+    lengths incl. over-long ones, coordinates in both layouts, binding values, interaction masks).  Stored: the sample
+    list itself (strings as unicode arrays), the collated batch, the split and the per-rank index orders."""
+    import tempfile
+    from protlig_dd.data import process_full_plinder as pfp
+    from torch.utils.data import DistributedSampler, random_split
+    rng = np.random.RandomState(21)
+    aa, sm = "ACDEFGHIKLMNPQRSTVWY", "CNOc1()=#SFl[]@H+-23"
+    out = {}
+    for tag, n, coords3 in (("a", 7, True), ("b", 5, False)):
+        samples = []
+        for i in range(n):
+            lp, ll = int(rng.randint(5, 90)), int(rng.randint(3, 40))
+            s = {"protein_seq": "".join(rng.choice(list(aa), lp)), "ligand_smiles": "".join(rng.choice(list(sm), ll)),
+                 "protein_coords": rng.randn(min(lp, 64), 3, 3).astype(np.float32) if coords3 else rng.randn(min(lp, 64), 3).astype(np.float32),
+                 "ligand_coords": rng.randn(int(rng.randint(2, 30)), 3).astype(np.float32),
+                 "binding_value": float(rng.randn()), "interaction_mask": (rng.rand(min(lp, 64)) > 0.5).astype(np.float32)}
+            samples.append(s)
+        path = os.path.join(tempfile.mkdtemp(), "synthetic.pt")
+        torch.save(samples, path)
+        ds = pfp.ImprovedProteinLigandDataset(path, max_protein_len=64, max_ligand_len=24)
+        batch = pfp.improved_protein_ligand_collate_fn([ds[i] for i in range(n)])
+        t = tag + "_"
+        out[t + "protein_seq"] = np.array([s["protein_seq"] for s in samples])
+        out[t + "ligand_smiles"] = np.array([s["ligand_smiles"] for s in samples])
+        out[t + "binding_in"] = np.array([s["binding_value"] for s in samples], dtype=np.float64)
+        for i, s in enumerate(samples):
+            out[f"{t}pc_{i}"], out[f"{t}lc_{i}"], out[f"{t}im_{i}"] = s["protein_coords"], s["ligand_coords"], s["interaction_mask"]
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                out[t + "batch_" + k] = v
+        assert batch["protein_seq"] == [s["protein_seq"] for s in samples]
+    # a batch without the optional fields and with only the ligand side
+    ds = pfp.ImprovedProteinLigandDataset.__new__(pfp.ImprovedProteinLigandDataset)
+    ds.data, ds.max_protein_len, ds.max_ligand_len = [{"ligand_smiles": "CCO"}, {"ligand_smiles": "c1ccccc1O"}], 16, 8
+    b = pfp.improved_protein_ligand_collate_fn([ds[0], ds[1]])
+    out["ligonly_keys"] = np.array(sorted(b.keys()))
+    out["ligonly_mask"] = b["ligand_mask"]
+    # split + shards
+    for n in (10, 37):
+        parts = random_split(list(range(n)), [int(0.8 * n), int(0.1 * n), n - int(0.8 * n) - int(0.1 * n)],
+                             generator=torch.Generator().manual_seed(42))
+        for nm, p in zip(("train", "val", "test"), parts):
+            out[f"split{n}_{nm}"] = np.array(list(p.indices), dtype=np.int64)
+        for world in (2, 3):
+            for rank in range(world):
+                sp = DistributedSampler(parts[0], num_replicas=world, rank=rank)
+                sp.set_epoch(2)
+                out[f"shard{n}_w{world}_r{rank}"] = np.array([parts[0].indices[i] for i in sp], dtype=np.int64)
+    save("g21_plinder_collate", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -1009,7 +1064,7 @@ def main():
                g6_predictor_steps, g7_timestep_embed, g8_ddit_block, g9_cross_attention, g10_sedd_model,
                g11_cross_model, g12_train_trajectory, g13_pc_sampler, g14_ema, g15_lr_schedule,
                g16_cross_train_trajectory, g17_bf16_autocast, g18_conditional_sampling,
-               g19_varlen_block, g20_sedd_conditioned):
+               g19_varlen_block, g20_sedd_conditioned, g21_plinder_collate):
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
         fn()

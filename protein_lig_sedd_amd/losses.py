@@ -133,7 +133,7 @@ def optimization_manager(config):
     return optimize_fn
 
 
-def _bind_trainer(state, noise, graph, optimize_fn):
+def _bind_trainer(state, noise, graph, optimize_fn, accum=1):
     """Build the flat-buffer trainer for a reference-style `state` dict (run_train_ddp_protlig_transf.py:207-213:
     optimizer / scaler / model / noise / ema / step) once, and make the objects the caller already holds —
     state['optimizer'], state['ema'] — views onto it."""
@@ -146,7 +146,7 @@ def _bind_trainer(state, noise, graph, optimize_fn):
     optim = dict(lr=opt.base_lr, beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
                  optimizer=opt.name, warmup=cfg.optim.warmup if cfg is not None else 0,
                  grad_clip=cfg.optim.grad_clip if cfg is not None else -1.0)
-    tr = SEDDTrainer(model, noise, graph, optim, ema_decay=ema.decay, ema=ema)
+    tr = SEDDTrainer(model, noise, graph, optim, ema_decay=ema.decay, ema=ema, accum=accum)
     tr.step_count = int(state['step'])
     tr._set_adam_steps(tr.step_count)
     opt.bind(tr)
@@ -154,18 +154,19 @@ def _bind_trainer(state, noise, graph, optimize_fn):
     return tr
 
 
-def get_step_fn(noise, graph, train, optimize_fn, accum):
+def get_step_fn(noise, graph, train, optimize_fn, accum, true_accumulation=False):
     """losses.py:74-117 on the fused path: the training branch is `SEDDTrainer.train_step` (loss -> backward into the flat
     gradient buffer -> RCCL all-reduce when data parallel -> one fused optimiser + EMA kernel), with the reference's
     return value and `state['step']` bookkeeping; the eval branch is the reference's EMA store / copy_to / restore
     around a no-grad loss.  `t=` / `perturbed_batch=` are optional replay arguments (parity tests)."""
-    if accum != 1:
+    if accum != 1 and not true_accumulation:
         raise NotImplementedError("gradient accumulation: the reference's step_fn resets its counter on every call "
-                                  "(losses.py:84), so it only ever worked for accum == 1; the fused step keeps that")
+                                  "(losses.py:84), so it only ever worked for accum == 1; pass true_accumulation=True for "
+                                  "the intended behaviour (k micro-steps of loss / k, one optimiser step)")
     loss_fn = get_loss_fn(noise, graph, train)
 
     def step_fn(state, batch, cond=None, esm_cond=None, mol_cond=None, t=None, perturbed_batch=None):
-        tr = state.get('trainer') or _bind_trainer(state, noise, graph, optimize_fn)
+        tr = state.get('trainer') or _bind_trainer(state, noise, graph, optimize_fn, accum)
         model = state['model']
         if train:
             cfg = getattr(optimize_fn, "config", None)
@@ -173,7 +174,7 @@ def get_step_fn(noise, graph, train, optimize_fn, accum):
                 tr.lr, tr.warmup, tr.grad_clip = float(cfg.optim.lr), cfg.optim.warmup, cfg.optim.grad_clip
             tr.step_count = int(state['step'])
             loss = tr.train_step(batch, t=t, perturbed_batch=perturbed_batch)
-            state['step'] = tr.step_count
+            state['step'] = tr.step_count   # (advances on the accum-th micro-step only)
         else:
             with torch.no_grad():
                 ema = state['ema']

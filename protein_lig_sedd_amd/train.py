@@ -105,7 +105,7 @@ class SEDDTrainer:
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
-                 process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False):
+                 process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False, accum=1):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
@@ -117,9 +117,16 @@ class SEDDTrainer:
             raise NotImplementedError(f'Optimizer {self.optimizer_name} not supported yet!')
         self.decoupled_wd = self.optimizer_name == "AdamW"
         if g("accum", 1) not in (None, 1):
-            raise NotImplementedError("gradient accumulation (training.accum != 1) is not supported by the fused step; "
-                                      "the reference's step_fn resets its counter every call (losses.py:84) and only "
-                                      "works for accum == 1 either")
+            raise NotImplementedError("gradient accumulation through the optimiser config (training.accum != 1): the "
+                                      "reference's step_fn resets its counter every call (losses.py:84) and only works "
+                                      "for accum == 1; pass accum=k to SEDDTrainer for real accumulation (opt-in)")
+        # accum = k > 1 (opt-in; what losses.py:80-115 was written to do before its counter reset broke it): k calls of
+        # train_step each add loss / k's gradients to the flat buffer — it is NOT zeroed in between — and the k-th call
+        # all-reduces once, steps the optimiser and returns the summed loss (the mean over the k micro-batches)
+        self.accum = int(accum)
+        if self.accum < 1:
+            raise ValueError("accum must be >= 1")
+        self._accum_iter, self._accum_loss = 0, None
         self.model, self.noise, self.graph = model, noise, graph
         # optional step -> lr callable (e.g. lr_scheduler.warmup_cosine_lr of the cross-attention trainer,
         # run_train_protlig_cross_att.py); default = losses.py:58-62 linear warm-up
@@ -202,15 +209,31 @@ class SEDDTrainer:
         return self.lr * min(step / self.warmup, 1.0) if self.warmup and self.warmup > 0 else self.lr
 
     def train_step(self, batch, t=None, perturbed_batch=None, u=None, esm_cond=None, mol_cond=None):
-        """One optimisation step (losses.py:80-115 with accum = 1). Returns the local loss (0-dim device tensor)."""
+        """One call of losses.py:80-115's step_fn.  accum == 1: one optimisation step, returns the local loss (0-dim
+        device tensor).  accum = k: a micro-step — the k-th call steps the optimiser and returns the accumulated loss,
+        the others return their own loss / k, as the reference's step_fn does."""
         fl = self.flat
-        fl.g.zero_()
+        if self._accum_iter == 0:
+            fl.g.zero_()
         self.model.train()
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                             mol_cond=mol_cond)
-        loss.backward()
+        if self.accum == 1:
+            loss.backward()
+            self.apply_gradients()
+            return loss.detach()
+        if self.overlap:
+            raise RuntimeError("gradient accumulation with SEDD_DP_OVERLAP=1: the per-block buckets would all-reduce "
+                               "every micro-step; use the default single all-reduce")
+        loss = loss / self.accum
+        loss.backward()   # every backward kernel ACCUMULATES into the flat gradient buffer
+        self._accum_iter += 1
+        self._accum_loss = loss.detach() if self._accum_loss is None else self._accum_loss + loss.detach()
+        if self._accum_iter < self.accum:
+            return loss.detach()
+        total, self._accum_iter, self._accum_loss = self._accum_loss, 0, None
         self.apply_gradients()
-        return loss.detach()
+        return total
 
     def apply_gradients(self, step=None):
         """all-reduce -> clip -> Adam(W) -> EMA on whatever the flat gradient buffer holds (losses.py:52-69 + :102).

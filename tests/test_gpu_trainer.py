@@ -297,3 +297,64 @@ def test_train_step_is_bit_reproducible():
         assert torch.equal(x, y), f"gradients of step {s}: {int((x != y).sum())} elements differ"
     assert torch.equal(pa, pb) and torch.equal(ea, eb)
     assert float(ga[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("cdt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_gradient_accumulation_equals_the_large_batch_step(cdt, tol):
+    """accum = k (opt-in; what losses.py:80-115 intends): k micro-steps of loss / k without zeroing the flat gradient
+    buffer, then ONE optimiser step == one step on the concatenated batch (mean over equal-sized micro-batches); the
+    non-stepping calls return loss / k and leave the weights alone; through get_step_fn with true_accumulation=True too."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib, losses
+    from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    D, H, C, nb, tokens, B, L, k = 128, 2, 64, 2, 25, 8, 64, 4
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=31)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randint(0, tokens, (B, L), generator=g).to(DEV)
+    t = (torch.rand(B, generator=g) * 0.9 + 0.05).to(DEV)
+    u = torch.rand(B, L, generator=g).to(DEV)
+    opt = dict(lr=1e-3, warmup=0, grad_clip=1.0, weight_decay=0.01)
+
+    def fresh(**kw):
+        m = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
+        m.load_state_dict({kk: v.clone() for kk, v in sd.items()}, strict=False)
+        return m, SEDDTrainer(m, noise, graph, opt, world_size=1, **kw)
+
+    _, big = fresh()
+    _, acc = fresh(accum=k)
+    for step in range(2):
+        lb = big.train_step(x0, t=t, u=u)
+        p_before = acc.flat.p.clone()
+        per = B // k
+        for i in range(k):
+            sl = slice(i * per, (i + 1) * per)
+            la = acc.train_step(x0[sl], t=t[sl], u=u[sl])
+            if i < k - 1:
+                assert torch.equal(acc.flat.p, p_before) and acc.step_count == step
+        assert acc.step_count == step + 1 and acc.ema.num_updates == step + 1
+        assert abs(float(la) - float(lb)) <= tol * abs(float(lb)) + 1e-6
+        assert rel_err(acc.flat.g, big.flat.g) < max(tol, 1e-4) * 3
+        assert rel_err(acc.flat.p, big.flat.p) < max(tol * 1e-1, 1e-5)
+    # reference call shapes: get_step_fn(..., accum) raises unless the opt-in is given
+    cfgo = types.SimpleNamespace(optim=types.SimpleNamespace(optimizer="AdamW", lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                                                             weight_decay=0.01, warmup=0, grad_clip=1.0))
+    with pytest.raises(NotImplementedError):
+        losses.get_step_fn(noise, graph, True, losses.optimization_manager(cfgo), k)
+    m, _ = fresh()
+    m2 = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
+    m2.load_state_dict({kk: v.clone() for kk, v in sd.items()}, strict=False)
+    state = dict(optimizer=losses.get_optimizer(cfgo, m2.parameters()), scaler=None, model=m2, noise=noise,
+                 ema=ExponentialMovingAverage(m2.parameters(), 0.9999), step=0)
+    step_fn = losses.get_step_fn(noise, graph, True, losses.optimization_manager(cfgo), k, true_accumulation=True)
+    _, one = fresh()
+    l1 = one.train_step(x0, t=t, u=u)
+    per = B // k
+    for i in range(k):
+        sl = slice(i * per, (i + 1) * per)
+        xt = graph.sample_transition(x0[sl], noise(t[sl])[0][:, None], u=u[sl])
+        lk = step_fn(state, x0[sl], t=t[sl], perturbed_batch=xt)
+        assert state["step"] == (1 if i == k - 1 else 0)
+    assert abs(float(lk) - float(l1)) <= tol * abs(float(l1)) + 1e-6
+    assert rel_err(state["trainer"].flat.p, one.flat.p) < max(tol * 1e-1, 1e-5)

@@ -241,3 +241,66 @@ def test_data_path_helpers():
                     ref.set_epoch(3)
                     got = data.distributed_indices(n, rank, world, shuffle=shuffle, seed=7, epoch=3, drop_last=drop_last)
                     assert got == list(ref), (n, world, shuffle, drop_last, rank)
+
+
+def test_g21_plinder_dataset_collate_split_and_shards(golden, tmp_path):
+    """`ProteinLigandDataset` / `protein_ligand_collate_fn` / `split_indices` / `BatchLoader` against the
+    reference's ImprovedProteinLigandDataset + improved_protein_ligand_collate_fn + random_split + DistributedSampler
+    (data/process_full_plinder.py:31-243, :293-301, :396-398) on the synthetic sample list of golden g21."""
+    import numpy as np
+    from protein_lig_sedd_amd import data
+    g = golden("g21_plinder_collate")
+    for tag, n in (("a", 7), ("b", 5)):
+        t = tag + "_"
+        samples = []
+        for i in range(n):
+            samples.append({"protein_seq": str(g.z[t + "protein_seq"][i]), "ligand_smiles": str(g.z[t + "ligand_smiles"][i]),
+                            "protein_coords": g.z[f"{t}pc_{i}"], "ligand_coords": g.z[f"{t}lc_{i}"],
+                            "binding_value": float(g.z[t + "binding_in"][i]), "interaction_mask": g.z[f"{t}im_{i}"]})
+        path = tmp_path / f"{tag}.pt"   # through a file, with the safe loader
+        torch.save([{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in s.items()} for s in samples], path)
+        ds = data.ProteinLigandDataset(str(path), max_protein_len=64, max_ligand_len=24)
+        assert len(ds) == n
+        batch = data.protein_ligand_collate_fn([ds[i] for i in range(n)])
+        ref_keys = {k[len(t + "batch_"):] for k in g.keys() if k.startswith(t + "batch_")}
+        assert ref_keys | {"protein_seq", "ligand_smiles"} == set(batch)       # strings: no token tensors invented
+        for k in ref_keys:
+            assert batch[k].dtype == g[t + "batch_" + k].dtype and torch.equal(batch[k], g[t + "batch_" + k]), k
+        assert batch["protein_seq"] == [s["protein_seq"] for s in samples]
+    with pytest.raises(FileNotFoundError):
+        data.ProteinLigandDataset(str(tmp_path / "missing.pt"))
+    # ligand-only samples, no optional fields
+    ds = data.ProteinLigandDataset([{"ligand_smiles": "CCO"}, {"ligand_smiles": "c1ccccc1O"}], 16, 8)
+    b = data.protein_ligand_collate_fn([ds[0], ds[1]])
+    assert sorted(b) == [str(k) for k in g.z["ligonly_keys"]] and torch.equal(b["ligand_mask"], g["ligonly_mask"])
+    # token-id lists: the trainer's batch keys, right-padded / truncated like the tokenizer calls
+    ds = data.ProteinLigandDataset([{"protein_seq": [5, 6, 7], "ligand_smiles": list(range(3, 15))},
+                                    {"protein_seq": list(range(4, 30)), "ligand_smiles": [9]}], 16, 8)
+    b = data.protein_ligand_collate_fn([ds[0], ds[1]], protein_pad_id=1, ligand_pad_id=2)
+    assert b["prot_tokens"].shape == (2, 16) and b["lig_tokens"].shape == (2, 8) and b["prot_tokens"].dtype == torch.int64
+    assert b["prot_tokens"][0].tolist() == [5, 6, 7] + [1] * 13 and b["prot_tokens"][1].tolist() == list(range(4, 20))
+    assert b["lig_tokens"][0].tolist() == list(range(3, 11)) and b["lig_tokens"][1].tolist() == [9] + [2] * 7
+    assert torch.equal(b["protein_mask"], (b["prot_tokens"] != 1).float())
+    cat = data.ddp_concat_batch(b["lig_tokens"], b["prot_tokens"])
+    assert cat.shape == (2, 24) and int(cat[0, 8]) == 5 + 2363
+    # seeded split and per-rank shards
+    for n in (10, 37):
+        tr, va, te = data.split_indices(n, 0.8, 0.1, 42)
+        for nm, got in (("train", tr), ("val", va), ("test", te)):
+            assert got == g[f"split{n}_{nm}"].tolist(), (n, nm)
+        for world in (2, 3):
+            for rank in range(world):
+                ld = data.BatchLoader(list(range(n)), tr, 4, collate_fn=lambda x: x, rank=rank, world=world, shuffle=True)
+                ld.set_epoch(2)
+                assert [i for bt in ld for i in bt] == g[f"shard{n}_w{world}_r{rank}"].tolist()
+                assert len(ld) == len(list(ld))
+    # loaders end to end: every training sample of the split exactly once over the ranks (up to the sampler's wrap-around)
+    samples = [{"protein_seq": list(range(1, 3 + i % 7)), "ligand_smiles": [3 + i]} for i in range(23)]
+    seen = []
+    for rank in range(2):
+        trl, val, tel = data.create_data_loaders(samples, batch_size=4, max_protein_len=8, max_ligand_len=4, rank=rank, world=2)
+        for bt in trl:
+            assert bt["prot_tokens"].shape[1] == 8 and bt["lig_tokens"].shape[1] == 4
+            seen += [int(v) - 3 for v in bt["lig_tokens"][:, 0]]
+    tr, _, _ = data.split_indices(23)
+    assert set(seen) == set(tr) and len(seen) == 2 * ((len(tr) + 1) // 2)
