@@ -894,9 +894,14 @@ __global__ void __launch_bounds__(256) attn_small_dkv_kernel(const T* __restrict
     small_store32<T>(dv + b * sh.kv_bs + row * sh.kv_ls + h * 32, av, 1.0f);
 }
 #undef SMALL_INDEX
-static bool attn_small_ok(int Lq, int Lk, int d, const int* cu) {
+// (the one-thread-per-row kernels move o / dout as 16-byte vectors: their strides and bases must be 16-byte multiples —
+// check_attn only asks o for 8 bytes in bf16 — else the tile kernels take the call as before)
+static bool attn_small_ok(int Lq, int Lk, int d, const int* cu, int dtype, int64_t o_bs, int64_t o_ls, const void* o,
+                          const void* dout) {
     static const bool off = getenv("SEDD_NO_SMALL_ATTN") != nullptr;  // A/B knob
-    return !off && !cu && d == 32 && Lq <= SMALL_L && Lk <= SMALL_L;
+    const int al = dtype == SEDD_BF16 ? 8 : 4;
+    const bool aligned = o_bs % al == 0 && o_ls % al == 0 && ((uintptr_t)o & 15) == 0 && ((uintptr_t)dout & 15) == 0;
+    return !off && !cu && d == 32 && Lq <= SMALL_L && Lk <= SMALL_L && aligned;
 }
 
 // ==================================================================================================== host
@@ -939,7 +944,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     if (B == 0) return SEDD_OK;
     SEDD_CHECK_ARG(q && k && v && o && lse, "attn_fwd: null pointer");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), nullptr, nullptr, cu, total};
-    if (attn_small_ok(Lq, Lk, d, cu)) {
+    if (attn_small_ok(Lq, Lk, d, cu, dtype, o_bs, o_ls, o, nullptr)) {
         const dim3 gs((unsigned)(((int64_t)B * H * Lq + 255) / 256));
         if (dtype == SEDD_BF16)
             hipLaunchKernelGGL(attn_small_fwd_kernel<bf16_t>, gs, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
@@ -978,7 +983,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     SEDD_CHECK_ARG(!rot_cos || Lq == Lk, "attn_bwd: the fused rotary gradient is for self-attention (Lq == Lk)");
     AttnShape sh{H, Lq, Lk, q_bs, q_ls, kv_bs, kv_ls, o_bs, o_ls, 1.0f / sqrtf((float)d), rot_cos, rot_sin, cu, total};
     hipStream_t st = (hipStream_t)stream;
-    if (attn_small_ok(Lq, Lk, d, cu) && !rot_cos) {
+    if (attn_small_ok(Lq, Lk, d, cu, dtype, o_bs, o_ls, o, dout) && !rot_cos) {
         const dim3 gsq((unsigned)(((int64_t)B * H * Lq + 255) / 256)), gsk((unsigned)(((int64_t)B * H * Lk + 255) / 256));
 #define SMALL_BWD(T)                                                                                                   \
         hipLaunchKernelGGL(attn_small_dq_kernel<T>, gsq, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,      \

@@ -202,7 +202,9 @@ class ProteinLigandDiffusionModel(nn.Module):
         key = None
         if self._ctx_step is not None and not torch.is_grad_enabled() and not self.training:
             # (the caller holds `indices` for the whole sampling run, so its storage identifies the conditioning input)
-            key = (track, indices.data_ptr(), indices._version, tuple(indices.shape))
+            # and sigma: a second call of the same step at another t (a corrector, a user loop) must not get this context
+            key = (track, indices.data_ptr(), indices._version, tuple(indices.shape), timesteps.data_ptr(),
+                   timesteps._version, tuple(timesteps.shape))
             hit = self._ctx_cache.get(key)
             if hit is not None:
                 self.context_cache_hits += 1

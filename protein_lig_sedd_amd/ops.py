@@ -96,6 +96,24 @@ def _cuda(*ts):
             raise RuntimeError("protein_lig_sedd_amd ops need CUDA(HIP) tensors: there is no CPU fallback")
 
 
+_SCRATCH = {}
+_SCRATCH_RETIRED = []
+
+
+def _scratch(kind, device, need):
+    """fp32 scratch of >= `need` floats for the cross-block reductions (fixed-order folds instead of atomics), one per
+    (kind, device, STREAM): launches on one stream are ordered, so consecutive calls share it; two streams on one GPU (a
+    training step beside an evaluation forward) get buffers of their own instead of racing on one.  A buffer that has to
+    grow is RETIRED, not freed — a HIP graph captured earlier may still hold its address."""
+    key = (kind, device.index, _stream())
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _SCRATCH_RETIRED.append(ws)
+        ws = _SCRATCH[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
 def _c(t, dtype=None):
     if t is None:
         return None
@@ -358,14 +376,9 @@ def embedding_bwd(dout, idx, dtable):
     need = lib().sedd_embedding_bwd_ws_floats(idx.numel(), D, V)  # fixed-order fold instead of atomics where supported
     ws = None
     if need and not _ATOMIC:
-        ws = _EMB_WS.get(dtable.device.index)
-        if ws is None or ws.numel() < need:
-            ws = _EMB_WS[dtable.device.index] = torch.empty(need, dtype=torch.float32, device=dtable.device)
+        ws = _scratch("emb", dtable.device, need)
     check(lib().sedd_embedding_bwd(_p(dout), _p(idx), _p(dtable), _p(ws), idx.numel(), D, V, _stream()),
           "sedd_embedding_bwd")
-
-
-_EMB_WS = {}
 
 
 def _mod_args(t):
@@ -555,9 +568,6 @@ def logits_epilogue_bwd_(dlogits, idx):
     return dlogits
 
 
-_COLSUM_ROWS_WS = {}
-
-
 def colsum(a, out=None, accumulate=False):
     """a [M, N] (row stride allowed) -> fp32 [N]; accumulate into `out` when given and accumulate=True."""
     M, N = a.shape
@@ -566,10 +576,7 @@ def colsum(a, out=None, accumulate=False):
         accumulate = False
     ws = None
     if M > 128 and not _ATOMIC:  # several row blocks: fixed-order fold out of a scratch instead of atomics
-        need = ((M + 127) // 128) * N
-        ws = _COLSUM_ROWS_WS.get(a.device.index)
-        if ws is None or ws.numel() < need:
-            ws = _COLSUM_ROWS_WS[a.device.index] = torch.empty(need, dtype=torch.float32, device=a.device)
+        ws = _scratch("colsum_rows", a.device, ((M + 127) // 128) * N)
     check(lib().sedd_colsum(_p(a), _dt(a), a.stride(0), _p(out), _p(ws), 1 if accumulate else 0, M, N, _stream()),
           "sedd_colsum")
     return out
@@ -624,7 +631,6 @@ def gemm_nt(A, B, bias=None, gelu=False, out=None, out_dtype=None, accumulate=Fa
     return (out, pre) if (gelu and want_pre) else out
 
 
-_COLSUM_WS = {}
 # SEDD_ATOMIC_REDUCTIONS=1: no scratches for the cross-tile sums (fp32 atomics instead of fixed-order folds) — an A/B knob
 _ATOMIC = bool(os.environ.get("SEDD_ATOMIC_REDUCTIONS"))
 
@@ -634,12 +640,7 @@ def _colsum_ws(like, M, N, colsum):
     consecutive launches on a stream reuse it (the fold that reads it is ordered before the next launch)."""
     if colsum is None or _ATOMIC:
         return None
-    need = ((M + 255) // 256) * N
-    key = like.device.index
-    ws = _COLSUM_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _COLSUM_WS[key] = torch.empty(need, dtype=torch.float32, device=like.device)
-    return ws
+    return _scratch("colsum", like.device, ((M + 255) // 256) * N)
 
 
 def gemm_nt_dgelu_supported(A, B, pre):
@@ -773,17 +774,10 @@ def gemm_tn_supported(A, B):
             and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 
-_TN_WS = {}
-
-
 def _tn_workspace(device):
-    """split-K scratch for sedd_gemm_tn: 256 partial tiles of 256 x 256 fp32 (64 MiB), one per device and stream user;
-    launches on one stream are ordered, so consecutive calls may share it."""
-    ws = _TN_WS.get(device)
-    if ws is None:
-        ws = torch.empty(256 * 256 * 256, dtype=torch.float32, device=device)
-        _TN_WS[device] = ws
-    return ws
+    """split-K scratch of the weight-gradient / small-shape GEMMs: 256 partial tiles of 256 x 256 fp32 (64 MiB), fixed
+    size, one per device and stream (see _scratch)."""
+    return _scratch("splitk", device, 256 * 256 * 256)
 
 
 def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):

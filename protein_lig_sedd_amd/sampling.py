@@ -152,6 +152,8 @@ class _GraphedStep:
             with torch.cuda.graph(self.graph):
                 self.x.copy_(fn(self.x, self.t, self.u))
         except RuntimeError as e:  # (torch.AcceleratorError is a RuntimeError)
+            self.graph = None      # drop the half-built graph object and the static buffers with it
+            self.x = self.t = self.u = None
             raise RuntimeError("hip_graph=True: the predictor update could not be captured — proj_fun or the model call "
                                "does host-side work under capture (a Python list / bool-mask index, .item(), a "
                                f"host-to-device copy ...): {e}") from e
@@ -202,14 +204,20 @@ def get_pc_sampler(graph, noise, batch_dims, predictor, steps, denoise=True, eps
                 # weights replaced through autograd-visible writes — load_state_dict, ema.copy_to — bump a version and
                 # force a new capture, the trainer's in-place flat-buffer updates keep the cached views current)
                 wsig = sum(p._version for p in model.parameters()) if hasattr(model, "parameters") else 0
-                key = (id(model), task, None if prot_indices is None else prot_indices.data_ptr(),
-                       None if lig_indices is None else lig_indices.data_ptr(), tuple(x.shape),
+
+                def tsig(ten):  # address AND extent: the allocator may hand a recycled address to a tensor of another shape
+                    return None if ten is None else (ten.data_ptr(), tuple(ten.shape), ten.dtype, ten._version)
+
+                key = (task, tsig(prot_indices), tsig(lig_indices), tuple(x.shape),
                        None if u0 is None else tuple(u0.shape), wsig)
-                if key not in graphed:
+                ent = graphed.get(key)
+                # the model is compared by identity through a weak reference (an id() can be recycled by a new object)
+                if ent is None or ent[0]() is not model:
                     mark(None)  # (the per-step context cache is host state: the captured step recomputes the context)
                     graphed.clear()
-                    graphed[key] = _GraphedStep(one, x, timesteps[0] * ones, u0)
-                x = graphed[key].run(x, timesteps[:steps, None, None] * ones, noise_seq, steps)
+                    import weakref
+                    ent = graphed[key] = (weakref.ref(model), _GraphedStep(one, x, timesteps[0] * ones, u0))
+                x = ent[1].run(x, timesteps[:steps, None, None] * ones, noise_seq, steps)
             for i in range(0 if use_graph else steps):
                 mark(i)
                 t = timesteps[i] * ones

@@ -335,17 +335,20 @@ def test_context_cache_is_per_step():
         b = cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
         assert len(calls) == 3 and cm.context_cache_hits == 1          # second call of the step reuses the context
         assert torch.equal(a, base1) and torch.equal(b, base1)
+        # a call of the SAME step at another sigma (a corrector at its own t, a user loop) must not get the cached context
+        b2 = cm(protein_indices=prot, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
+        assert len(calls) == 4 and cm.context_cache_hits == 1 and torch.equal(b2, base2)
         cm.sampling_step(1)                                            # new step = new sigma: recomputed
         c = cm(protein_indices=prot, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
-        assert len(calls) == 4 and torch.equal(c, base2)
+        assert len(calls) == 5 and torch.equal(c, base2)
         prot2 = prot.clone()                                           # other conditioning input: its own entry
         cm(protein_indices=prot2, ligand_indices=lig, timesteps=s2, mode="ligand_given_protein")
-        assert len(calls) == 5
+        assert len(calls) == 6
         cm.sampling_step(None)
         assert cm._ctx_cache == {}
     cm.sampling_step(0)
     cm.train()
     cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
     cm(protein_indices=prot, ligand_indices=lig, timesteps=s1, mode="ligand_given_protein")
-    assert len(calls) == 7 and cm.context_cache_hits == 1              # training / autograd: no caching
+    assert len(calls) == 8 and cm.context_cache_hits == 1              # training / autograd: no caching
     cm.sampling_step(None)
