@@ -202,6 +202,22 @@ def gpu_cfg1(dev):
     torch.cuda.synchronize()
     out["train_step_s"] = (time.perf_counter() - t0) / 10
     out["train_tokens_per_s"] = B * L / out["train_step_s"]
+    # the same step replayed as ONE HIP graph (SEDDTrainer(hip_graph=True): bit-identical results, tested): at 1024 tokens
+    # per step the eager step is bound by the host's launch rate
+    for cdt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        m2 = _SEDD(cfg, compute_dtype=cdt).to(dev)
+        randomize(m2, 1)
+        for hg in (False, True):
+            tr2 = SEDDTrainer(m2, noise, graph, dict(lr=3e-4, warmup=100, grad_clip=1.0), ema_decay=0.9999, world_size=1,
+                              hip_graph=hg)
+            for _ in range(5):
+                tr2.train_step(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                tr2.train_step(x)
+            torch.cuda.synchronize()
+            out[f"train_step_s_{tag}" + ("_hip_graph" if hg else "")] = (time.perf_counter() - t0) / 20
     out["sampled_seqs_per_s"] = B / out["euler_128_steps_plus_denoise_s"]
     return out
 

@@ -183,7 +183,10 @@ int sedd_ln_modulate_bwd_noalloc(const void* dy, int dy_dtype, const float* x, c
  * ln_modulate.  Dropout (p = model.dropout in training): either keep = uint8 [M,D] keep-mask supplied by the caller,
  * or keep == NULL and p_drop > 0: the mask is generated in the kernel from a counter-based hash of (seed, element
  * index), so the backward call with the same seed reproduces it and no mask is stored; keep == NULL and p_drop == 0:
- * inference.  inv_keep = 1/(1-p) in both dropout forms. */
+ * inference.  inv_keep = 1/(1-p) in both dropout forms. 
+ * A seed with bit 63 set is INDIRECT: bits 47..0 = device address of a uint64 salt, bits 62..48 = a site number; the
+ * kernels then hash with salt + site * 0xD1B54A32D192ED03 — launch arguments frozen by a HIP-graph capture still give
+ * fresh masks when the salt in device memory changes between replays. */
 int sedd_gate_residual_fwd(const float* residual, const void* a, int a_dtype, const void* gate, int mod_dtype,
                            int64_t mod_stride, const uint8_t* keep, float inv_keep, uint64_t seed, float p_drop,
                            float* out, int64_t M, int64_t L, int D, sedd_stream_t stream);
@@ -379,6 +382,21 @@ int sedd_adamw_ema_double_step(float* p, const float* g, float* m, float* v, flo
                                const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
                                sedd_stream_t stream);
+/* sedd_adamw_ema_step / _double_step (steps = 1 | 2) with the per-step scalars read from DEVICE memory: hyper = six floats
+ * {1 - lr*wd (decoupled) or 1, lr / bias_corr1, 1 / sqrt(bias_corr2), 1 - ema_decay, and the second step's lr / bias_corr1,
+ * 1 / sqrt(bias_corr2)}, as sedd_adamw_step_scalars computes them.  No counterpart in the reference: for callers that
+ * capture a whole train step (losses.py:80-115) in a HIP graph, where launch arguments are frozen at capture. */
+int sedd_adamw_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                            const float* clip_coef, const float* hyper, float grad_scale, float beta1, float beta2,
+                            float eps, float weight_decay, int decoupled, int steps, int64_t n, sedd_stream_t stream);
+/* writes hyper_dev[0..5] = v0..v5 and *salt_dev = salt (either may be NULL) from a one-thread launch: the values travel as
+ * launch arguments, so the per-step scalars of a captured step reach device memory in stream order without a host buffer
+ * that has to outlive the call.  salt_dev: the uint64 an INDIRECT dropout seed points at (sedd_gate_residual_fwd). */
+int sedd_write_step_scalars(float* hyper_dev, uint64_t* salt_dev, float v0, float v1, float v2, float v3, float v4,
+                            float v5, uint64_t salt, sedd_stream_t stream);
+/* host arithmetic only: the six scalars above for optimiser step `step` (1-based), written to HOST memory out6_host. */
+int sedd_adamw_step_scalars(float lr, float beta1, float beta2, float weight_decay, int decoupled, int step,
+                            float ema_decay, float* out6_host);
 /* out[0] = sum_r w[r / L] * x[r]  (losses.py:29: (dsigma[:, None] * loss).mean() with w_b = dsigma_b / M).
  * fp32, deterministic two-stage; ws fp32 [1024] caller workspace. */
 int sedd_batch_weighted_sum(const float* x, const float* w, int64_t M, int64_t L, float* ws, float* out,

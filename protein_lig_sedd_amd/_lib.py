@@ -70,6 +70,9 @@ SIGNATURES = {
     "sedd_attn_varlen_bwd": "pppppp" + "pppp" + "p" + "iiiiii" + "lll" + "p",
     "sedd_adamw_ema_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
     "sedd_adamw_ema_double_step": "ppppppp" + "ffffff" + "ii" + "f" + "lp",
+    "sedd_adamw_ema_step_dev": "pppppppp" + "fffff" + "ii" + "lp",
+    "sedd_adamw_step_scalars": "ffffiifp",
+    "sedd_write_step_scalars": "ppfffffflp",
     "sedd_sumsq_clip": "plffppp",
     "sedd_ema_update": "ppflp",
     "sedd_batch_weighted_sum": "ppllppp",

@@ -140,6 +140,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+// A seed with bit 63 set is INDIRECT: bits 47..0 hold the device address of a uint64 salt, bits 62..48 a site number, and
+// the effective seed is salt + site * odd constant — a step captured in a HIP graph replays with fresh masks when the host
+// (or a node of the graph) changes the salt in device memory, while the launch arguments stay what they were at capture.
+__device__ __forceinline__ uint64_t resolve_seed(uint64_t seed) {
+    if ((seed >> 63) == 0) return seed;
+    const uint64_t salt = *reinterpret_cast<const uint64_t*>(seed & 0x0000FFFFFFFFFFFFull);
+    return (salt + ((seed >> 48) & 0x7FFFull) * 0xD1B54A32D192ED03ull) & 0x7FFFFFFFFFFFFFFFull;
+}
 __device__ __forceinline__ float4 keep4_hashed(uint64_t seed, int64_t off, uint32_t thr16, float inv_keep) {
     const uint64_t q = (uint64_t)off >> 2;
     const uint32_t h0 = mix32(mix32((uint32_t)q ^ (uint32_t)seed) + (uint32_t)(q >> 32) + (uint32_t)(seed >> 32));
@@ -171,6 +179,7 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                                                          const float* dx_add, float* __restrict__ ws, int64_t nchunk,
                                                          int64_t L, int D, int CR, GateBwdArgs ga) {
     __shared__ float red[3 * NV * 256];
+    if (GATE && ga.thr16) ga.seed = resolve_seed(ga.seed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cpb = (L + CR - 1) / CR;
     const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;
@@ -513,6 +522,7 @@ __global__ void __launch_bounds__(TPB) gate_res_fwd_kernel(const float* __restri
                                                            const uint8_t* __restrict__ keep, float inv_keep,
                                                            uint64_t seed, uint32_t thr16,
                                                            float* __restrict__ out, int64_t M, int64_t L, int D) {
+    if (thr16) seed = resolve_seed(seed);
     const int64_t nvec = M * (int64_t)(D / 4);
     const int dv = D / 4;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * TPB) {
@@ -569,6 +579,7 @@ __global__ void __launch_bounds__(TPB) gate_res_ln_mod_fwd_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (row >= M) return;
+    if (thr16) seed = resolve_seed(seed);
     const int64_t b = row / L;
     float4 v[NV];
     float s = 0.f;
@@ -664,6 +675,7 @@ __global__ void __launch_bounds__(TPB) gate_res_bwd_kernel(const float* __restri
                                                            TA* __restrict__ da, float* __restrict__ ws,
                                                            float* __restrict__ ws2, int64_t L, int D, int CR) {
     __shared__ float red[(TPB / 64) * 256];
+    if (thr16) seed = resolve_seed(seed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cpb = (L + CR - 1) / CR;
     const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;

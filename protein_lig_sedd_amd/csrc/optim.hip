@@ -24,7 +24,15 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
                                                         const float* __restrict__ clip, float gscale, float decay_mul,
                                                         float l2, float beta1, float beta2, float eps, float step_size,
                                                         float inv_bc2_sqrt, float one_m_ema, int64_t n,
-                                                        float step_size2, float inv_bc2_sqrt2) {
+                                                        float step_size2, float inv_bc2_sqrt2,
+                                                        const float* __restrict__ hyper) {
+    // hyper (optional, device memory): the per-step scalars of a step whose launch arguments were frozen by a HIP-graph
+    // capture — {decay_mul, step_size, inv_bc2_sqrt, one_m_ema, step_size2, inv_bc2_sqrt2}, written by the host before
+    // each replay
+    if (hyper) {
+        decay_mul = hyper[0]; step_size = hyper[1]; inv_bc2_sqrt = hyper[2]; one_m_ema = hyper[3];
+        step_size2 = hyper[4]; inv_bc2_sqrt2 = hyper[5];
+    }
     const float cs = (clip ? clip[0] : 1.0f) * gscale;
     const int64_t nv = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
@@ -61,10 +69,30 @@ __global__ void __launch_bounds__(TPB) adamw_ema_kernel(float* __restrict__ p, c
     }
 }
 
+static void adamw_scalars(float lr, float beta1, float beta2, float weight_decay, int decoupled, int step,
+                          float ema_decay, float out[6]) {
+    for (int s = 0; s < 2; ++s) {
+        const double bc1 = 1.0 - pow((double)beta1, step + s), bc2 = 1.0 - pow((double)beta2, step + s);
+        out[1 + 3 * s] = (float)((double)lr / bc1);
+        out[2 + 3 * s] = (float)(1.0 / sqrt(bc2));
+    }
+    out[0] = decoupled ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
+    out[3] = 1.0f - ema_decay;
+}
+
+// the six per-step scalars of sedd_adamw_ema_step / _double_step as the kernel consumes them (host arithmetic only):
+// what a caller writes into the `hyper` device buffer of sedd_adamw_ema_step_dev before each replay of a captured step
+extern "C" int sedd_adamw_step_scalars(float lr, float beta1, float beta2, float weight_decay, int decoupled, int step,
+                                       float ema_decay, float* out6_host) {
+    SEDD_CHECK_ARG(out6_host && step >= 1, "adamw_step_scalars: bad arguments");
+    adamw_scalars(lr, beta1, beta2, weight_decay, decoupled, step, ema_decay, out6_host);
+    return SEDD_OK;
+}
+
 static int adamw_ema_launch(int ns, float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
                             const float* clip_coef, float grad_scale, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int decoupled, int step, float ema_decay, int64_t n,
-                            sedd_stream_t stream) {
+                            sedd_stream_t stream, const float* hyper = nullptr) {
     SEDD_CHECK_ARG(n >= 0 && step >= 1, "adamw_ema_step: bad n=%ld step=%d", (long)n, step);
     if (n % 4 != 0) {
         sedd_set_error("adamw_ema_step: n=%ld must be a multiple of 4 (pad the flat buffer)", (long)n);
@@ -72,23 +100,20 @@ static int adamw_ema_launch(int ns, float* p, const float* g, float* m, float* v
     }
     if (n == 0) return SEDD_OK;
     SEDD_CHECK_ARG(p && g && m && v, "adamw_ema_step: null pointer");
-    float step_size[2], inv_bc2_sqrt[2];
-    for (int s = 0; s < 2; ++s) {
-        const double bc1 = 1.0 - pow((double)beta1, step + s), bc2 = 1.0 - pow((double)beta2, step + s);
-        step_size[s] = (float)((double)lr / bc1);
-        inv_bc2_sqrt[s] = (float)(1.0 / sqrt(bc2));
-    }
-    const float decay_mul = decoupled ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
+    float sc[6];
+    adamw_scalars(lr, beta1, beta2, weight_decay, decoupled, step, ema_decay, sc);
+    const float step_size[2] = {sc[1], sc[4]}, inv_bc2_sqrt[2] = {sc[2], sc[5]};
+    const float decay_mul = sc[0];
     const float l2 = decoupled ? 0.0f : weight_decay;
     const dim3 grid(sedd_grid_for(n / 4, TPB, 256 * 16));
     if (ns == 1)
         hipLaunchKernelGGL(adamw_ema_kernel<1>, grid, dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)p_bf16,
                            clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size[0], inv_bc2_sqrt[0],
-                           1.0f - ema_decay, n, 0.f, 0.f);
+                           1.0f - ema_decay, n, 0.f, 0.f, hyper);
     else
         hipLaunchKernelGGL(adamw_ema_kernel<2>, grid, dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, ema, (bf16_t*)p_bf16,
                            clip_coef, grad_scale, decay_mul, l2, beta1, beta2, eps, step_size[0], inv_bc2_sqrt[0],
-                           1.0f - ema_decay, n, step_size[1], inv_bc2_sqrt[1]);
+                           1.0f - ema_decay, n, step_size[1], inv_bc2_sqrt[1], hyper);
     SEDD_LAUNCH_CHECK();
     return SEDD_OK;
 }
@@ -109,6 +134,37 @@ extern "C" int sedd_adamw_ema_double_step(float* p, const float* g, float* m, fl
                                           int64_t n, sedd_stream_t stream) {
     return adamw_ema_launch(2, p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay,
                             decoupled, step, ema_decay, n, stream);
+}
+
+// sedd_adamw_ema_step / _double_step (steps = 1 | 2) with the per-step scalars read from DEVICE memory (`hyper`: six
+// floats, see sedd_adamw_step_scalars) instead of the launch arguments: for callers that capture the whole train step in
+// a HIP graph, where launch arguments are frozen at capture (lr / bias corrections / EMA decay change every step).
+extern "C" int sedd_adamw_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, void* p_bf16,
+                                       const float* clip_coef, const float* hyper, float grad_scale, float beta1,
+                                       float beta2, float eps, float weight_decay, int decoupled, int steps, int64_t n,
+                                       sedd_stream_t stream) {
+    SEDD_CHECK_ARG(hyper, "adamw_ema_step_dev: hyper is null");
+    SEDD_CHECK_ARG(steps == 1 || steps == 2, "adamw_ema_step_dev: steps must be 1 or 2");
+    return adamw_ema_launch(steps, p, g, m, v, ema, p_bf16, clip_coef, grad_scale, 0.f, beta1, beta2, eps, weight_decay,
+                            decoupled, 1, 0.f, n, stream, hyper);
+}
+
+// The per-step device scalars of a captured train step, written by a one-thread launch whose values travel as launch
+// ARGUMENTS (no host buffer has to outlive the call, nothing synchronises): hyper[0..5] for sedd_adamw_ema_step_dev and
+// the dropout salt of the indirect seeds (sedd_gate_residual_fwd).  Either destination may be NULL.
+__global__ void write_step_scalars_kernel(float* hyper, uint64_t* salt_dst, float v0, float v1, float v2, float v3,
+                                          float v4, float v5, uint64_t salt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (hyper) { hyper[0] = v0; hyper[1] = v1; hyper[2] = v2; hyper[3] = v3; hyper[4] = v4; hyper[5] = v5; }
+        if (salt_dst) *salt_dst = salt;
+    }
+}
+extern "C" int sedd_write_step_scalars(float* hyper_dev, uint64_t* salt_dev, float v0, float v1, float v2, float v3,
+                                       float v4, float v5, uint64_t salt, sedd_stream_t stream) {
+    hipLaunchKernelGGL(write_step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper_dev, salt_dev, v0, v1,
+                       v2, v3, v4, v5, salt);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
 }
 
 __global__ void __launch_bounds__(TPB) ema_update_kernel(float* __restrict__ s, const float* __restrict__ p, float omd,

@@ -458,8 +458,19 @@ class DropSeed:
     same mask in the kernel (sedd_gate_residual_fwd / _bwd)."""
     __slots__ = ("seed", "p")
     _counter = 0
+    # while a train step is being CAPTURED as a HIP graph: (device uint64 salt tensor, sites handed out so far) — the seeds
+    # are then indirect (bit 63 | site << 48 | address of the salt, see sedd_gate_residual_fwd): the launch arguments the
+    # capture freezes stay valid, and the masks change with the salt the trainer writes before every replay
+    _indirect = None
 
     def __init__(self, p, seed=None):
+        if seed is None and DropSeed._indirect is not None:
+            salt, site = DropSeed._indirect
+            site += 1
+            if site >= 1 << 15:
+                raise RuntimeError("more than 32767 dropout sites in one captured step")
+            DropSeed._indirect = (salt, site)
+            seed = (1 << 63) | (site << 48) | salt.data_ptr()
         if seed is None:
             DropSeed._counter += 1
             # the rank is mixed in: data-parallel ranks are seeded identically (same initial weights) but must draw
@@ -473,7 +484,7 @@ class DropSeed:
 def _keep_args(keep):
     """-> (mask pointer, seed, p_drop) for a uint8 mask tensor, a DropSeed or None."""
     if isinstance(keep, DropSeed):
-        return None, keep.seed, keep.p
+        return None, (keep.seed - (1 << 64) if keep.seed >> 63 else keep.seed), keep.p  # (ctypes int64 carries the bits)
     return _p(keep), 0, 0.0
 
 
@@ -926,6 +937,32 @@ def adamw_ema_double_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, be
                                            float(grad_scale), float(lr), float(beta1), float(beta2), float(eps),
                                            float(weight_decay), 1 if decoupled else 0, int(step), float(ema_decay),
                                            p.numel(), _stream()), "sedd_adamw_ema_double_step")
+
+
+def adamw_step_scalars(lr, beta1, beta2, weight_decay, decoupled, step, ema_decay):
+    """the six per-step scalars of the optimiser kernel (host arithmetic of the library, so the captured and the eager
+    step use the very same numbers)."""
+    import ctypes
+    out = (ctypes.c_float * 6)()
+    check(lib().sedd_adamw_step_scalars(float(lr), float(beta1), float(beta2), float(weight_decay), 1 if decoupled else 0,
+                                        int(step), float(ema_decay), ctypes.addressof(out)), "sedd_adamw_step_scalars")
+    return [float(x) for x in out]
+
+
+def write_step_scalars(hyper_dev, salt_dev, scalars, salt):
+    """hyper_dev[0..5] <- scalars, salt_dev[0] <- salt, in stream order (values travel as launch arguments)."""
+    salt = int(salt) & 0x7FFFFFFFFFFFFFFF
+    check(lib().sedd_write_step_scalars(_p(hyper_dev), _p(salt_dev), *[float(x) for x in scalars], salt, _stream()),
+          "sedd_write_step_scalars")
+
+
+def adamw_ema_step_dev(p, g, m, v, ema, p_bf16, clip_coef, hyper, grad_scale, beta1, beta2, eps, weight_decay, steps=1,
+                       decoupled=True):
+    """sedd_adamw_ema_step / _double_step (steps = 1 | 2) with lr / bias corrections / EMA decay read from the device
+    buffer `hyper` (see write_step_scalars): the form a HIP-graph capture of the train step launches."""
+    check(lib().sedd_adamw_ema_step_dev(_p(p), _p(g), _p(m), _p(v), _p(ema), _p(p_bf16), _p(clip_coef), _p(hyper),
+                                        float(grad_scale), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                        1 if decoupled else 0, int(steps), p.numel(), _stream()), "sedd_adamw_ema_step_dev")
 
 
 def ema_update_(shadow, p, one_minus_decay):

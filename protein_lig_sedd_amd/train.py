@@ -105,7 +105,8 @@ class SEDDTrainer:
     optim: namespace/dict with lr, beta1, beta2, eps, weight_decay, warmup, grad_clip (configs/*.yaml `optim:`)."""
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
-                 process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False, accum=1):
+                 process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False, accum=1,
+                 hip_graph=False):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
@@ -127,6 +128,10 @@ class SEDDTrainer:
         if self.accum < 1:
             raise ValueError("accum must be >= 1")
         self._accum_iter, self._accum_loss = 0, None
+        # hip_graph=True (opt-in, not in the reference): train_step runs as one replayed HIP graph, see _graphed_step
+        self.hip_graph, self.graph_warmup = bool(hip_graph), 2
+        self._graphs, self._graph_calls, self._hyper, self._salt, self._salt_count = {}, {}, None, None, 0
+        self._capturing, self._always_norm = False, False
         self.model, self.noise, self.graph = model, noise, graph
         # optional step -> lr callable (e.g. lr_scheduler.warmup_cosine_lr of the cross-attention trainer,
         # run_train_protlig_cross_att.py); default = losses.py:58-62 linear warm-up
@@ -213,6 +218,19 @@ class SEDDTrainer:
         device tensor).  accum = k: a micro-step — the k-th call steps the optimiser and returns the accumulated loss,
         the others return their own loss / k, as the reference's step_fn does."""
         fl = self.flat
+        if self.hip_graph and self.accum == 1:
+            inputs = {k: v for k, v in dict(batch=batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
+                                            mol_cond=mol_cond).items() if v is not None}
+
+            def body(batch, t=None, perturbed_batch=None, u=None, esm_cond=None, mol_cond=None):
+                fl.g.zero_()
+                self.model.train()
+                loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
+                                    mol_cond=mol_cond)
+                loss.backward()
+                return (loss,)
+
+            return self._graphed_step(body, inputs)[0]
         if self._accum_iter == 0:
             fl.g.zero_()
         self.model.train()
@@ -238,19 +256,98 @@ class SEDDTrainer:
     def apply_gradients(self, step=None):
         """all-reduce -> clip -> Adam(W) -> EMA on whatever the flat gradient buffer holds (losses.py:52-69 + :102).
         step: the 1-based optimiser step this is (default: the next one)."""
-        fl = self.flat
         self._reduce_gradients()
+        self._launch_update(*self._host_advance(step))
+        self.flat.refresh_compute_weights()
+
+    # ---- the optimiser pass in two halves: host bookkeeping (what changes from step to step) and the launches ----------
+    def _host_advance(self, step=None):
+        """-> (lr, ema decay, optimiser step, kernel steps): pure host arithmetic, no launches."""
         self.step_count = self.step_count + 1 if step is None else int(step)
+        self.ema.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
+        return self.current_lr(self.step_count), decay, self.step_count, 1
+
+    def _launch_update(self, lr, decay, opt_step, ns):
+        """clip -> Adam(W) -> EMA -> bf16 copy.  Inside a captured step (self._hyper set) the per-step scalars come from
+        device memory, so the frozen launch arguments stay valid for every replay."""
+        fl = self.flat
         gscale = 1.0 / self.world
         clip = None
         if self.grad_clip is not None and self.grad_clip >= 0:
             ops.sumsq_clip(fl.g, gscale, self.grad_clip, self._ws, self._norm)
             clip = self._norm[1:]
-        self.ema.num_updates += 1
-        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
-        ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, self.current_lr(self.step_count),
-                           self.beta1, self.beta2, self.eps, self.wd, self.step_count, decay, self.decoupled_wd)
-        fl.refresh_compute_weights()
+        elif self._always_norm:
+            ops.sumsq_clip(fl.g, gscale, -1.0, self._ws, self._norm)
+        if self._capturing:
+            ops.adamw_ema_step_dev(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, self._hyper, gscale, self.beta1, self.beta2,
+                                   self.eps, self.wd, ns, self.decoupled_wd)
+        elif ns == 2:
+            ops.adamw_ema_double_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
+                                      self.eps, self.wd, opt_step, decay, self.decoupled_wd)
+        else:
+            ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
+                               self.wd, opt_step, decay, self.decoupled_wd)
+
+    # ---- whole-step HIP graph ------------------------------------------------------------------------------------------
+    def _graphed_step(self, body, inputs):
+        """Run `body(**inputs)` (zero grads -> loss -> backward; returns a tuple of loss tensors) + the optimiser pass as ONE
+        replayed HIP graph.  A small-batch step is thousands of launches of a few microseconds and the Python between them
+        is the limiter (cfg 3 at batch 4: ~36 ms of host time per 41 ms step); a replay is one launch.  What changes from
+        step to step lives in device memory: the inputs (static buffers, copied per call), lr / bias corrections / EMA
+        decay (`_hyper`, sedd_adamw_ema_step_dev) and the dropout salt (indirect seeds, ops.DropSeed) — both written by
+        sedd_write_step_scalars right before the replay; t / corruption noise come from torch's graph-safe generator.
+        The first `graph_warmup` calls run eagerly (allocator pools, scratches and weight caches settle), the next one
+        captures.  Single process only (the RCCL all-reduce stays outside captures here)."""
+        if self.dp:
+            raise RuntimeError("hip_graph=True: single-process training only")
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(inputs.items()))
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._graph_calls.get(key, 0)
+            self._graph_calls[key] = n + 1
+            if n < self.graph_warmup:
+                out = body(**inputs)
+                self._launch_update(*self._host_advance())
+                self.flat.refresh_compute_weights()
+                return tuple(o.detach() for o in out)
+            dev = self.flat.p.device
+            if self._hyper is None:
+                self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+                self._salt = torch.zeros(1, dtype=torch.int64, device=dev)
+            static = {k: v.clone() for k, v in inputs.items()}
+            graph = torch.cuda.CUDAGraph()
+            ops.DropSeed._indirect = (self._salt, 0)
+            self._capturing = True
+            try:
+                with torch.cuda.graph(graph):
+                    out = body(**static)
+                    self._launch_update(0.0, 0.0, 1, self._kernel_steps())
+            except RuntimeError as e:
+                graph = None
+                raise RuntimeError(f"hip_graph=True: the train step could not be captured ({e})") from e
+            finally:
+                ops.DropSeed._indirect = None
+                self._capturing = False
+            ent = self._graphs[key] = (graph, static, tuple(o.detach() for o in out))
+        graph, static, out = ent
+        for k, v in inputs.items():
+            static[k].copy_(v)
+        lr, decay, opt_step, ns = self._host_advance()
+        self._salt_count += 1
+        ops.write_step_scalars(self._hyper, self._salt,
+                               ops.adamw_step_scalars(lr, self.beta1, self.beta2, self.wd, self.decoupled_wd, opt_step, decay),
+                               torch.initial_seed() * 0x9E3779B97F4A7C15 + self._salt_count * 0xA24BAED4963EE407)
+        graph.replay()
+        return tuple(o.clone() for o in out)
+
+    def _kernel_steps(self):
+        return 1
+
+    def reset_graphs(self):
+        """drop the captured steps (after anything a capture froze has changed: shapes are keyed, module structure,
+        trainable set and hyper-parameters other than lr / step / EMA decay are not)."""
+        self._graphs, self._graph_calls = {}, {}
 
     def _reduce_gradients(self):
         """Finish the gradient all-reduce (SUM; the 1/world averaging is folded into the optimiser kernel's grad_scale):
@@ -432,17 +529,21 @@ class CrossAttTrainer(SEDDTrainer):
     trainer pass raw sequence strings to the ESM / MolFormer encoders (network downloads) and are out of scope."""
 
     def __init__(self, model, noise, graph_prot, graph_lig, optim, task="joint", ema_decay=0.9999, sampling_eps=1e-3,
-                 world_size=None, process_group=None, lr_schedule=None, double_step=True, per_sample_weighting=False):
+                 world_size=None, process_group=None, lr_schedule=None, double_step=True, per_sample_weighting=False,
+                 hip_graph=False):
         if task in ("protein_given_ligand", "protein_only"):
             self.freeze_model(model, "lig")
         elif task in ("ligand_given_protein", "ligand_only"):
             self.freeze_model(model, "prot")
         super().__init__(model, noise, graph_prot, optim, ema_decay=ema_decay, sampling_eps=sampling_eps,
-                         world_size=world_size, process_group=process_group, overlap=False, lr_schedule=lr_schedule)
+                         world_size=world_size, process_group=process_group, overlap=False, lr_schedule=lr_schedule,
+                         hip_graph=hip_graph)
+        self._always_norm = True  # (this trainer reports the gradient norm whether or not it clips)
         self.graph_prot, self.graph_lig = graph_prot, graph_lig
         self.task, self.double_step, self.per_sample_weighting = task, double_step, per_sample_weighting
         self.sampling_eps = sampling_eps
         self.opt_steps = 0  # Adam's own step counter (advances twice per iteration with double_step)
+        self._graphs_by_task, self._graph_calls_by_task = {}, {}
 
     def _adam_steps(self):
         return self.opt_steps
@@ -493,33 +594,51 @@ class CrossAttTrainer(SEDDTrainer):
             return dsigma[:, None] * ((mp + ml) / 2), dsigma[:, None] * mp, dsigma[:, None] * ml
         raise NotImplementedError(f"Task {task} not implemented")
 
+    def _kernel_steps(self):
+        return 2 if self.double_step else 1
+
+    def _host_advance(self, step=None):
+        self.step_count += 1
+        lr = self.current_lr(self.step_count - 1) if self.lr_schedule is not None else self.current_lr(self.step_count)
+        self.ema.num_updates += 1
+        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
+        first = self.opt_steps + 1
+        self.opt_steps += 2 if self.double_step else 1  # Q2: the same clipped gradients twice; the EMA takes the first
+        return lr, decay, first, self._kernel_steps()   # step's weights (one pass)
+
     def train_step(self, batch, task=None, t=None, perturbed=None):
         """:299-333.  Returns loss (or (loss, loss_prot, loss_lig) for 'joint') as 0-dim device tensors."""
         task = task or self.task
         fl = self.flat
-        fl.g.zero_()
-        self.model.train()
-        out = self.calc_loss(batch, task, t=t, perturbed=perturbed)
-        loss = out[0].mean() if task == "joint" else out.mean()
-        loss.backward()
-        if self.dp:
-            dist.all_reduce(fl.g, group=self.pg)
-        self.step_count += 1
-        gscale = 1.0 / self.world
-        ops.sumsq_clip(fl.g, gscale, self.grad_clip if self.grad_clip is not None else -1.0, self._ws, self._norm)
-        clip = self._norm[1:] if (self.grad_clip is not None and self.grad_clip >= 0) else None
-        lr = self.current_lr(self.step_count - 1) if self.lr_schedule is not None else self.current_lr(self.step_count)
-        self.ema.num_updates += 1
-        decay = min(self.ema_decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
-        self.opt_steps += 1
-        if self.double_step:  # Q2: the same clipped gradients twice; the EMA takes the first step's weights (one pass)
-            ops.adamw_ema_double_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2,
-                                      self.eps, self.wd, self.opt_steps, decay, self.decoupled_wd)
-            self.opt_steps += 1
+
+        def body(t=None, **tensors):
+            b = {k[2:]: v for k, v in tensors.items() if k.startswith("b_")}
+            pert = {k[2:]: v for k, v in tensors.items() if k.startswith("p_")}
+            fl.g.zero_()
+            self.model.train()
+            out = self.calc_loss(b, task, t=t, perturbed=pert)
+            loss = out[0].mean() if task == "joint" else out.mean()
+            loss.backward()
+            if task == "joint":
+                return loss, out[1].mean(), out[2].mean()
+            return (loss,)
+
+        inputs = {"b_" + k: v for k, v in batch.items() if torch.is_tensor(v)}
+        inputs.update({"p_" + k: v for k, v in (perturbed or {}).items()})
+        if t is not None:
+            inputs["t"] = t
+        if self.hip_graph:
+            saved, self._graphs = self._graphs, self._graphs_by_task.setdefault(task, {})
+            saved_calls, self._graph_calls = self._graph_calls, self._graph_calls_by_task.setdefault(task, {})
+            try:
+                out = self._graphed_step(body, inputs)
+            finally:
+                self._graphs, self._graph_calls = saved, saved_calls
         else:
-            ops.adamw_ema_step(fl.p, fl.g, fl.m, fl.v, fl.ema, fl.pc, clip, gscale, lr, self.beta1, self.beta2, self.eps,
-                               self.wd, self.opt_steps, decay, self.decoupled_wd)
-        fl.refresh_compute_weights()
-        if task == "joint":
-            return loss.detach(), out[1].mean().detach(), out[2].mean().detach()
-        return loss.detach()
+            out = body(**inputs)
+            if self.dp:
+                dist.all_reduce(fl.g, group=self.pg)
+            self._launch_update(*self._host_advance())
+            fl.refresh_compute_weights()
+            out = tuple(o.detach() for o in out)
+        return out if task == "joint" else out[0]

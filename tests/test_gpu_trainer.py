@@ -358,3 +358,71 @@ def test_gradient_accumulation_equals_the_large_batch_step(cdt, tol):
         assert state["step"] == (1 if i == k - 1 else 0)
     assert abs(float(lk) - float(l1)) <= tol * abs(float(l1)) + 1e-6
     assert rel_err(state["trainer"].flat.p, one.flat.p) < max(tol * 1e-1, 1e-5)
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_hip_graph_train_step_is_bit_identical_to_eager(cdt):
+    """hip_graph=True: the whole train step (zero grads -> corrupt -> forward -> fused loss -> backward -> clip -> AdamW
+    -> EMA) replayed as ONE HIP graph, with lr / bias corrections / EMA decay read from device memory, must leave exactly
+    the bits the eager step leaves — losses, weights, moments, EMA — through warm-up calls, the capture and replays, with
+    a warm-up lr schedule that changes every step."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    D, H, C, nb, tokens, B, L, steps = 128, 2, 64, 2, 25, 4, 64, 7
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=41)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randint(0, tokens, (B, L), generator=g).to(DEV) for _ in range(steps)]
+    ts = [(torch.rand(B, generator=g) * 0.9 + 0.05).to(DEV) for _ in range(steps)]
+    us = [torch.rand(B, L, generator=g).to(DEV) for _ in range(steps)]
+
+    def run(hg):
+        m = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+        tr = SEDDTrainer(m, noise, graph, dict(lr=1e-3, warmup=5, grad_clip=1.0, weight_decay=0.01), world_size=1, hip_graph=hg)
+        losses = [float(tr.train_step(xs[i], t=ts[i], u=us[i])) for i in range(steps)]
+        torch.cuda.synchronize()
+        return losses, tr
+
+    le, te = run(False)
+    lg, tg = run(True)
+    assert len(tg._graphs) == 1 and tg.step_count == steps and tg.ema.num_updates == steps
+    assert lg == le
+    for name in ("p", "m", "v", "ema"):
+        assert torch.equal(getattr(tg.flat, name), getattr(te.flat, name)), name
+    if tg.flat.pc is not None:
+        assert torch.equal(tg.flat.pc, te.flat.pc)
+    assert tg.grad_norm() == te.grad_norm()
+    # another input signature (no explicit u: torch's generator draws the corruption inside the graph) captures its own graph
+    for _ in range(4):
+        l = tg.train_step(xs[0], t=ts[0])
+    assert len(tg._graphs) == 2 and torch.isfinite(l)
+
+
+def test_hip_graph_train_step_draws_fresh_dropout_masks():
+    """dropout under a captured step: the seeds frozen in the graph are indirect, the salt they point at is rewritten before
+    every replay — the same inputs give different losses step after step (fresh masks), and training still converges."""
+    from protein_lig_sedd_amd import graph_lib, noise_lib
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.train import SEDDTrainer
+    D, H, C, nb, tokens, B, L = 128, 2, 64, 2, 25, 8, 64
+    cfg = _cfg(D, H, C, nb, tokens)
+    cfg.model.dropout = 0.3
+    m = _SEDD(cfg, compute_dtype=torch.float32).to(DEV)
+    m.load_state_dict({k: v.clone() for k, v in seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=42).items()}, strict=False)
+    graph, noise = graph_lib.Absorbing(tokens), noise_lib.LogLinearNoise(eps=1e-3).to(DEV)
+    tr = SEDDTrainer(m, noise, graph, dict(lr=0.0, warmup=0, grad_clip=1.0), world_size=1, hip_graph=True)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randint(0, tokens, (B, L), generator=g).to(DEV)
+    t = (torch.rand(B, generator=g) * 0.5 + 0.4).to(DEV)
+    u = torch.rand(B, L, generator=g).to(DEV)
+    losses = [float(tr.train_step(x0, t=t, u=u)) for _ in range(8)]   # lr = 0: only the dropout masks differ
+    replayed = losses[tr.graph_warmup:]
+    assert len(set(replayed)) == len(replayed), replayed
+    assert max(replayed) - min(replayed) < 0.5 * abs(replayed[0])
+    tr.lr = 2e-3
+    first = float(tr.train_step(x0, t=t, u=u))
+    for _ in range(30):
+        last = float(tr.train_step(x0, t=t, u=u))
+    assert last < first
