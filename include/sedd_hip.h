@@ -408,6 +408,10 @@ int sedd_ema_update(float* shadow, const float* p, float one_minus_decay, int64_
  * gradients, as clip_grad_norm_ does); max_norm < 0: no clipping, out[1] is left untouched. */
 int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float max_norm, float* ws, float* out,
                     sedd_stream_t stream);
+/* the last step of sedd_sumsq_clip on its own: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)) from a sum of
+ * squares that is already in out[0] — the sharded optimiser (reduce-scatter -> optimiser on the 1/N shard -> all-gather)
+ * all-reduces the per-shard sums into out[0] first; clip_grad_norm_ of losses.py:65-66 over the WHOLE model. */
+int sedd_clip_from_sumsq(float* out, float gscale, float max_norm, sedd_stream_t stream);
 
 #ifdef __cplusplus
 }

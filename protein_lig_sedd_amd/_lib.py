@@ -74,6 +74,7 @@ SIGNATURES = {
     "sedd_adamw_step_scalars": "ffffiifp",
     "sedd_write_step_scalars": "ppfffffflp",
     "sedd_sumsq_clip": "plffppp",
+    "sedd_clip_from_sumsq": "pffp",
     "sedd_ema_update": "ppflp",
     "sedd_batch_weighted_sum": "ppllppp",
 }

@@ -74,7 +74,10 @@ __device__ __forceinline__ void rows_compact(bool active, int r, int* s_cnt, uns
 // loops (row stride V*esize bytes: conflict-free or 2-way for the vocabularies in use; strides that are a multiple of
 // 32 bytes fall back to the group kernels).  Row sums are evaluated in the same association order as the group
 // kernels' xor-shuffle tree, so both layouts return identical bits.
-template <int VP> struct RowsCfg { static constexpr int ROWS = VP == 64 ? 128 : 256; };
+#ifndef SEDD_ROWS_PER_BLOCK
+#define SEDD_ROWS_PER_BLOCK 256
+#endif
+template <int VP> struct RowsCfg { static constexpr int ROWS = VP == 64 ? (SEDD_ROWS_PER_BLOCK > 128 ? 128 : SEDD_ROWS_PER_BLOCK) : SEDD_ROWS_PER_BLOCK; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -227,6 +227,20 @@ extern "C" int sedd_sumsq_clip(const float* g, int64_t n, float gscale, float ma
     return SEDD_OK;
 }
 
+// clip coefficient from an already-reduced sum of squares: out[1] = min(1, max_norm / (sqrt(out[0]) * gscale + 1e-6)) —
+// sedd_sumsq_clip's last step on its own, for the sharded optimiser (each rank reduces its shard with max_norm < 0, the
+// partial sums are all-reduced into out[0], then this).  max_norm < 0 leaves out[1] alone.
+__global__ void clip_from_sumsq_kernel(float* out, float gscale, float max_norm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && max_norm >= 0.f)
+        out[1] = fminf(1.0f, max_norm / (sqrtf(out[0]) * gscale + 1e-6f));
+}
+extern "C" int sedd_clip_from_sumsq(float* out, float gscale, float max_norm, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(out, "clip_from_sumsq: null pointer");
+    hipLaunchKernelGGL(clip_from_sumsq_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, gscale, max_norm);
+    SEDD_LAUNCH_CHECK();
+    return SEDD_OK;
+}
+
 // ---- loss reduction: sum_r w[r / L] * x[r] --------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB) wsum_stage1(const float* __restrict__ x, const float* __restrict__ w, int64_t M,
                                                    int64_t L, float* __restrict__ ws) {

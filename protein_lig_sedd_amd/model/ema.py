@@ -19,6 +19,7 @@ class ExponentialMovingAverage:
         self.num_updates = 0 if use_num_updates else None
         self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
         self.collected_params = []
+        self._before_read = None  # set by a sharded trainer: gathers the shadow's shards before it is read as a whole
 
     def current_decay(self):
         """decay that the NEXT update will use after incrementing num_updates (ema.py:38-42)."""
@@ -47,6 +48,8 @@ class ExponentialMovingAverage:
         version counter, which is what the compute-dtype weight cache of model/layers.py is keyed on — a forward after
         copy_to must see the EMA weights in every Linear, not a stale bf16 copy of the training weights."""
         parameters = [p for p in parameters if p.requires_grad]
+        if self._before_read is not None:
+            self._before_read()
         with torch.no_grad():
             for s_param, param in zip(self.shadow_params, parameters):
                 param.copy_(s_param)
@@ -63,6 +66,8 @@ class ExponentialMovingAverage:
                 _drop_weight_cache(param)
 
     def state_dict(self):
+        if self._before_read is not None:
+            self._before_read()
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
 
     def load_state_dict(self, state_dict):

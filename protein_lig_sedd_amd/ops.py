@@ -921,6 +921,11 @@ def sumsq_clip(g, gscale=1.0, max_norm=0.0, ws=None, out=None):
     return out
 
 
+def clip_from_sumsq(out, gscale, max_norm):
+    check(lib().sedd_clip_from_sumsq(_p(out), float(gscale), float(max_norm), _stream()), "sedd_clip_from_sumsq")
+    return out
+
+
 def adamw_ema_step(p, g, m, v, ema, p_bf16, clip_coef, grad_scale, lr, beta1, beta2, eps, weight_decay, step, ema_decay,
                    decoupled=True):
     """decoupled=True: AdamW (p *= 1 - lr*wd); False: torch.optim.Adam's L2 form (g += wd*p before the moments)."""

@@ -39,7 +39,7 @@ def main(out_path):
         t = [(torch.rand(B, generator=g) * 0.9 + 0.05).to(dev) for _ in range(3)]
         u = [torch.rand(B, L, generator=g).to(dev) for _ in range(3)]
 
-        def run(force, overlap, cdt):
+        def run(force, overlap, cdt, **kw):
             os.environ["SEDD_DP_FORCE"] = "1" if force else "0"
             os.environ["SEDD_DP_OVERLAP"] = "1" if overlap else "0"
             torch.manual_seed(3)
@@ -49,10 +49,14 @@ def main(out_path):
                     if p.dim() >= 2:
                         p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())).to(dev) * 0.05)
             tr = SEDDTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(dev), graph_lib.Absorbing(25),
-                             dict(lr=1e-3, warmup=0, grad_clip=1.0, weight_decay=0.01), world_size=1)
+                             dict(lr=1e-3, warmup=0, grad_clip=1.0, weight_decay=0.01), world_size=1, **kw)
             assert tr.dp == force and tr.overlap == (force and overlap)
             losses = [float(tr.train_step(x0[i], t=t[i], u=u[i])) for i in range(3)]
             avg = float(tr.reduce_loss(torch.tensor(losses[-1], device=dev)))
+            if kw.get("zero1"):
+                assert tr.zero1 and tr._shards_dirty
+                sd_ = tr.state_dict()                      # gathers moments / EMA (RCCL all-gather over the 1-rank group)
+                assert not tr._shards_dirty and sd_["step"] == 3
             torch.cuda.synchronize()
             return losses, tr.flat.p.clone(), tr.flat.ema.clone(), tr.flat.m.clone(), avg
 
@@ -68,6 +72,22 @@ def main(out_path):
                     "bit_identical": bool(same), "losses": got[0], "base_losses": base[0],
                     "max_abs_param_diff": float((got[1] - base[1]).abs().max())}
                 ok = ok and same
+        # sharded optimiser (reduce-scatter -> clip / AdamW / EMA on the shard -> all-gather) and bf16 gradient exchange over
+        # RCCL: with one rank the shard is the whole buffer, so zero1 in fp32 must leave the single-process bits; bf16
+        # gradients round every gradient element once (loss of step 1 identical, weights within bf16 gradient rounding)
+        for cdt in (torch.float32, torch.bfloat16):
+            base = run(False, False, cdt)
+            got = run(True, False, cdt, zero1=True)
+            same = got[0] == base[0] and all(torch.equal(got[i], base[i]) for i in (1, 2, 3))
+            res["cases"][f"zero1/{str(cdt).split('.')[-1]}"] = {"bit_identical": bool(same), "losses": got[0], "base_losses": base[0]}
+            ok = ok and same
+            for z1 in (False, True):
+                got = run(True, False, cdt, zero1=z1, grad_comm_dtype=torch.bfloat16)
+                rel = float((got[1] - base[1]).norm() / base[1].norm())
+                close = got[0][0] == base[0][0] and rel < 1e-3 and all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(got[0], base[0]))
+                res["cases"][f"bf16_grads{'_zero1' if z1 else ''}/{str(cdt).split('.')[-1]}"] = {
+                    "close": bool(close), "rel_param_diff": rel, "losses": got[0], "base_losses": base[0]}
+                ok = ok and close
         # resume through get_step_fn's adoption path: an EMA whose shadow differs from the weights survives the DP binding
         from protein_lig_sedd_amd.model.ema import ExponentialMovingAverage
         os.environ.update(SEDD_DP_FORCE="1", SEDD_DP_OVERLAP="0")

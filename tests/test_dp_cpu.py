@@ -82,6 +82,37 @@ def _worker(rank, world, port, q):
         fl.g.copy_(torch.arange(fl.n, dtype=torch.float32) * (rank + 1))
         tr._reduce_gradients()
         assert torch.equal(fl.g, expect)
+        # 3b. the cheaper exchanges: bf16 gradients and / or reduce-scatter onto this rank's shard (zero1), then the
+        #     all-gather that follows the sharded optimiser — every rank must end with the same whole buffers
+        os.environ["SEDD_DP_OVERLAP"] = "0"
+        for comm_dt in (torch.float32, torch.bfloat16):
+            for z1 in (False, True):
+                m3 = _SEDD(_cfg(), compute_dtype=torch.float32)
+                tr3 = SEDDTrainer(m3, noise_lib.LogLinearNoise(), graph_lib.Absorbing(25), dict(lr=1e-3), world_size=world,
+                                  grad_comm_dtype=comm_dt, zero1=z1)
+                f3 = tr3.flat
+                assert tr3.zero1 == z1 and f3.n % (64 * (world if z1 else 1)) == 0
+                lo, hi = tr3.shard
+                assert (hi - lo) * (world if z1 else 1) == f3.n and lo == (rank * (hi - lo) if z1 else 0)
+                base = ((torch.arange(f3.n, dtype=torch.float32) % 97) - 48.0) / 64.0   # bf16-exact values
+                f3.g.copy_(base * (rank + 1))
+                tr3._exchange_gradients()
+                want = base * sum(r + 1 for r in range(world))
+                assert torch.equal(f3.g[lo:hi], want[lo:hi]), (comm_dt, z1)
+                if not z1:
+                    assert torch.equal(f3.g, want)
+                else:
+                    # what the sharded optimiser leaves: each rank's own slice of p / m / v / ema is new, the rest stale
+                    for flat in (f3.p, f3.m, f3.v, f3.ema):
+                        flat.zero_()
+                        flat[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) + 1
+                    tr3._gather_flat(f3.p)
+                    assert torch.equal(f3.p, torch.arange(f3.n, dtype=torch.float32) + 1)
+                    tr3._shards_dirty = True
+                    sd3 = tr3.ema.state_dict()          # reading the EMA as a whole gathers the shards first
+                    assert torch.equal(f3.ema, torch.arange(f3.n, dtype=torch.float32) + 1) and not tr3._shards_dirty
+                    assert torch.equal(f3.m, f3.ema) and torch.equal(f3.v, f3.ema) and len(sd3["shadow_params"]) == len(f3.params)
+        os.environ["SEDD_DP_OVERLAP"] = "1"
         # 4. scalar loss all-reduce(AVG)
         assert abs(float(tr.reduce_loss(torch.tensor(float(rank)))) - 0.5) < 1e-6
         # 5. batch sharding + sharded sampling gather
