@@ -14,7 +14,8 @@
  *  - `dtype` arguments take SEDD_F32 or SEDD_BF16 and describe the activation/logit element type; reductions
  *    and all transcendental maths are fp32.
  *  - return value: 0 on success, <0 = sedd_status; sedd_last_error() gives a thread-local message.
- *  - re-entrant; no mutable global state.
+ *  - re-entrant; no mutable global state (exceptions, documented at their declarations: sedd_gemm_set_cu_budget and the
+ *    file-scope scratch of sedd_ln_modulate_bwd_noalloc).
  */
 #ifndef SEDD_HIP_H
 #define SEDD_HIP_H
@@ -314,6 +315,14 @@ int sedd_gemm_nn_dgelu(const void* A, int64_t lda, const void* B, int64_t ldb, v
 int sedd_gemm_nn_dmul(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                       int out_dtype, const void* mul, float* colsum, float* colsum_ws, int64_t M, int64_t N, int64_t K,
                       sedd_stream_t stream);
+/* CUs the persistent big-tile bf16 GEMM launches (sedd_gemm_nt / _nn / _tn and their fused forms) may count on: a
+ * multiple of 8 in [8, 256], default 256 (or the environment's SEDD_GEMM_CUS).  Process-wide setting, not a per-call
+ * argument — the one piece of mutable state in this library besides the no-alloc scratch; set it before launching, not
+ * concurrently with launches.  No counterpart in the reference: a data-parallel trainer that overlaps RCCL collectives
+ * with backward (run_train_ddp_protlig_transf.py:197's DDP buckets) leaves the collective's workgroups a few CUs so that
+ * a one-block-per-CU GEMM launch still fits one round. */
+int sedd_gemm_set_cu_budget(int cus);
+int sedd_gemm_get_cu_budget(void);
 /* Weight gradient of nn.Linear (autograd of the Linear layers above; the reference gets it from
  * torch.nn.functional.linear's backward): C[M,N] (+)= A[K,M]^T * B[K,N] with A = dY [tokens, out_features] and
  * B = X [tokens, in_features] row-major as the forward left them ("TN": the reduction index is the row), so no

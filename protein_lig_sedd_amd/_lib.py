@@ -62,6 +62,7 @@ SIGNATURES = {
     "sedd_gemm_nn_ws": "plplpliipilllplp",
     "sedd_gemm_nt_rotary": "plplpliipippiiilllp",
     "sedd_gemm_nn_dgelu": "plplpliippplllp",
+    "sedd_gemm_set_cu_budget": "i",
     "sedd_gemm_nt_dmul": "plplpliippplllp",
     "sedd_gemm_nn_dmul": "plplpliippplllp",
     "sedd_attn_fwd": "pppppp" + "iiiiii" + "llllll" + "p",
@@ -102,6 +103,8 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = [_T[c] for c in sig]
         fn.restype = ctypes.c_int
+    L.sedd_gemm_get_cu_budget.argtypes = []
+    L.sedd_gemm_get_cu_budget.restype = ctypes.c_int
     L.sedd_ln_bwd_chunks.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.sedd_ln_bwd_chunks.restype = ctypes.c_int64
     L.sedd_embedding_bwd_ws_floats.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]

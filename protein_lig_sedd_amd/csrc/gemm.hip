@@ -1204,10 +1204,27 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float4* __rest
 // S x (A bytes: every A panel is read by S XCDs) + B traffic, where a B slice of <= 2.5 MB stays L2-resident (read once
 // per XCD) and a larger one is streamed again every round.  fc1 forward (A 50 MB, B 4.7 MB, 6 rounds): S = 1 -> 276 MB
 // (measured 294), S = 2 -> 119 MB.
+// CUs the persistent big-tile launches may count on (default: all 256).  A data-parallel trainer that overlaps RCCL
+// collectives with backward lowers it (multiples of 8: one CU fewer per XCD keeps the tile -> XCD map): a GEMM block needs a
+// whole CU, so with a collective's workgroups resident a 256-block launch runs a second round for the blocks that found
+// no CU (2x its time, tools/cu_share_probe.py); with the budget below the free CUs it stays one round.
+static int g_cu_budget = []() {
+    const char* e = getenv("SEDD_GEMM_CUS");
+    const int v = e ? atoi(e) : 256;
+    return v >= 8 && v <= 256 ? v / 8 * 8 : 256;
+}();
+static inline int cu_budget() { return g_cu_budget; }
+extern "C" int sedd_gemm_set_cu_budget(int cus) {
+    SEDD_CHECK_ARG(cus >= 8 && cus <= 256 && cus % 8 == 0, "gemm_set_cu_budget: %d is not a multiple of 8 in [8, 256]", cus);
+    g_cu_budget = cus;
+    return SEDD_OK;
+}
+extern "C" int sedd_gemm_get_cu_budget(void) { return g_cu_budget; }
+
 static int choose_csplit(int64_t tm, int64_t tn, int64_t tiles, int64_t M, int64_t N, int64_t K) {
     static const char* ov = getenv("SEDD_GEMM_CSPLIT");
     if (tiles < 512 || tiles % 8) return 1;
-    const double A = 2.0 * (double)M * (double)K, B = 2.0 * (double)N * (double)K, rounds = (double)tiles / 256.0;
+    const double A = 2.0 * (double)M * (double)K, B = 2.0 * (double)N * (double)K, rounds = (double)tiles / cu_budget();
     int best = 1;
     double bc = 1e300;
     for (int S = 1; S <= 4; S *= 2) {
@@ -1223,7 +1240,7 @@ static int choose_csplit(int64_t tm, int64_t tn, int64_t tiles, int64_t M, int64
 // tiles * slices <= 256 (one round of persistent blocks), every slice a whole number of K tiles, at least 16 of them
 static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
     const int64_t nkt = K / BIG_BK;
-    int64_t sk = tiles > 0 ? 256 / tiles : 1;
+    int64_t sk = tiles > 0 ? cu_budget() / tiles : 1;
     if (sk > nkt / 16) sk = nkt / 16;
     if (sk < 1) sk = 1;
     const int64_t per = (nkt + sk - 1) / sk;
@@ -1369,7 +1386,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             const int64_t t256 = tm * ((N + 255) / 256), t128 = tm * ((N + 127) / 128);
             // cost ~ (number of chip-wide rounds) x (tile work); the 256-wide tile does twice the work per round, at
             // ~13 % better efficiency per flop (measured: N = 2304 prefers 4.5 rounds of 256 over 9 rounds of 128)
-            const double c256 = (double)((t256 + 255) / 256) * 2.0, c128 = (double)((t128 + 255) / 256) * 1.15;
+            const int cus = cu_budget();
+            const double c256 = (double)((t256 + cus - 1) / cus) * 2.0, c128 = (double)((t128 + cus - 1) / cus) * 1.15;
             bool wide = N > 128 && c256 <= c128;
             if (getenv("SEDD_GEMM_WIDE") && N > 128) wide = atoi(getenv("SEDD_GEMM_WIDE")) != 0;  // (A/B experiments)
             // rotary epilogue: the 128-wide tile has the registers to keep two passes of cos / sin rows in flight (the
@@ -1383,7 +1401,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             if (accumulate && out_dtype == SEDD_F32) big_splitk(tiles, K, &splitk, &kper);
             SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_nt: too many tiles");
             // one persistent block per CU (the operand ring takes most of a CU's LDS)
-            const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
+            const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < cus ? tiles : cus)));
             if (splitk == 1) tn |= (int64_t)choose_csplit(tm, tn, tiles, M, N, K) << 20;  // (tn is only passed on from here)
 #define BIG_LAUNCH(TO, BN_, NST)                                                                                     \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, NST, false, 0>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,     \
@@ -1650,7 +1668,7 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
         if (workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) slabs = (float4*)workspace;
         else if (!accumulate) { splitk = 1; kper = K; }
     }
-    const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < 256 ? tiles : 256)));
+    const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < cu_budget() ? tiles : cu_budget())));
 #define TN_LAUNCH(TO, BN_)                                                                                           \
     hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, 0>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \

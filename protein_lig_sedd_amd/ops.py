@@ -679,6 +679,11 @@ def gemm_nt_dgelu(A, B, pre, colsum=None):
     return out
 
 
+def set_gemm_cu_budget(cus):
+    """CUs the persistent bf16 GEMM launches count on (multiple of 8, <= 256); process-wide (see sedd_gemm_set_cu_budget)."""
+    check(lib().sedd_gemm_set_cu_budget(int(cus)), "sedd_gemm_set_cu_budget")
+
+
 def gemm_dmul_shapes_ok(M, N, K, dtype):
     """whether the fused `dU = (dY W2) * gelu'` launch (sedd_gemm_nn_dmul / _nt_dmul) will take an [M, K] x [K, N] product
     of freshly allocated bf16 tensors — decided in the forward pass, which then stores gelu' instead of the pre-activation."""

@@ -77,6 +77,10 @@ class FlatState:
         return [self.view(self.ema, i) for i in range(len(self.params))]
 
 
+def fl_is_cuda(flat):
+    return flat.p.is_cuda
+
+
 def init_distributed():
     """Bootstrap from torch.distributed.run's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), as
     run_train_ddp_protlig_transf.py:160-163 does; backend "nccl" is RCCL on ROCm."""
@@ -182,6 +186,9 @@ class SEDDTrainer:
         # costs less than that and nothing at all at N = 1.
         self.overlap = overlap and self.dp and os.environ.get("SEDD_DP_OVERLAP", "0") == "1"
         self.zero1 = self.zero1 and self.dp
+        if self.overlap and fl_is_cuda(self.flat):
+            # leave the collective's workgroups a CU per XCD: the one-block-per-CU GEMMs then still fit one round
+            ops.set_gemm_cu_budget(int(os.environ.get("SEDD_GEMM_CUS", "248")))
         if self.overlap and (self.zero1 or self.grad_comm_dtype != torch.float32):
             raise ValueError("SEDD_DP_OVERLAP=1 (per-block buckets) excludes zero1 / bf16 gradient exchange")
         self.rank = dist.get_rank(process_group) if (self.dp and dist.is_initialized()) else 0

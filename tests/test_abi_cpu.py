@@ -41,7 +41,8 @@ def test_header_symbols_exported_and_signatures_match():
     assert len(protos) >= 35
     for name, (ret, sig) in protos.items():
         assert hasattr(L, name), f"libsedd_hip.so does not export {name}"
-        if name in ("sedd_abi_version", "sedd_last_error", "sedd_ln_bwd_chunks", "sedd_embedding_bwd_ws_floats"):
+        if name in ("sedd_abi_version", "sedd_last_error", "sedd_ln_bwd_chunks", "sedd_embedding_bwd_ws_floats",
+                    "sedd_gemm_get_cu_budget"):
             continue
         assert name in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {name}"
         assert _lib.SIGNATURES[name] == sig, f"{name}: ctypes '{_lib.SIGNATURES[name]}' vs header '{sig}'"
@@ -84,6 +85,8 @@ def test_argument_validation_without_gpu():
     assert L.sedd_adamw_ema_double_step(None, None, None, None, None, None, None, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1,
                                         0.999, 6, None) == -2                       # n % 4
     assert L.sedd_ln_modulate_fwd(p, p, None, None, None, 0, 0, p, 0, None, None, 4, 2, 4100, None) == -2
+    assert L.sedd_gemm_get_cu_budget() == 256 and L.sedd_gemm_set_cu_budget(250) == -1 and L.sedd_gemm_set_cu_budget(0) == -1
+    assert L.sedd_gemm_set_cu_budget(248) == 0 and L.sedd_gemm_get_cu_budget() == 248 and L.sedd_gemm_set_cu_budget(256) == 0
     assert L.sedd_ln_bwd_chunks(64 * 512, 512) == 64 * 8   # 64-row chunks from 16384 rows up
     assert L.sedd_ln_bwd_chunks(4 * 512, 512) == 4 * 16     # 32-row chunks below
     assert L.sedd_ln_bwd_chunks(10 * 33, 33) == 10 * 2

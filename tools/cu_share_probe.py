@@ -18,13 +18,16 @@ def gemm_time(n=10):
     for _ in range(n): ops.gemm_nt(A, B, out=C)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for _ in range(5): ops.gemm_nt(A, B, out=C)
-torch.cuda.synchronize()
-print(f"alone: {gemm_time():.1f} us per launch", flush=True)
-for nwg in (1, 8, 32, 64):
+for budget in (256, 248, 240):
+  ops.set_gemm_cu_budget(budget)
+  for _ in range(5): ops.gemm_nt(A, B, out=C)
+  torch.cuda.synchronize()
+  print(f"CU budget {budget}: alone {gemm_time():.1f} us per launch", flush=True)
+  for nwg in (1, 8, 16, 64):
+    if nwg > 256 - budget and budget != 256: continue
     # occupy for 6 ms (600000 ticks of 10 ns); give the occupying kernel 0.5 ms to become resident, then time 10 GEMMs
     P.probe_occupy(nwg, 600000, sink.data_ptr(), side.cuda_stream)
     import time; time.sleep(0.0005)
     t = gemm_time()
     torch.cuda.synchronize()
-    print(f"{nwg:3d} occupying workgroups resident: {t:.1f} us per launch", flush=True)
+    print(f"   {nwg:3d} occupying workgroups resident: {t:.1f} us per launch", flush=True)
