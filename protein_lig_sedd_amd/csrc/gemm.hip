@@ -463,7 +463,10 @@ extern "C" int sedd_debug_gemm_phase(uint64_t* host_dst) {
 // DG: 0 = forward epilogues, 1 = EPI_DGELU (pre-activation in, gelu' computed here), 2 = EPI_DMUL (multiplier in),
 //     3 = forward with SEDD_EPI_BIAS_GELU_GRAD (a kernel of its own: the 256-wide tiles sit at the register limit and a
 //     run-time choice between the two GELU epilogues spilled in every instantiation)
-template <typename TO, int BN_, int NST, bool TN, int DG, int NW = 8, bool NNB = false, bool ROT = false>
+// BM_: rows of the output tile — 256, or 128 (NT / NN forms with the plain forward epilogues only) for outputs whose
+//     256-row tiles would leave most of the chip idle (the dual-track model at batch 4: [2048, 1024] is 64 tiles of
+//     256 x 128 = a quarter of the CUs, [512, 1024] sixteen).
+template <typename TO, int BN_, int NST, bool TN, int DG, int NW = 8, bool NNB = false, bool ROT = false, int BM_ = 256>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             const bf16_t* __restrict__ B, int64_t ldb,
@@ -475,11 +478,12 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                             float* __restrict__ colsum, RotArgs rot) {
     // ntn_cs = column tiles | (column split of the XCD map << 20), see big_tile_map / choose_csplit
     const int ntn = ntn_cs & 0xfffff, csplit = ntn_cs >> 20;
-    constexpr int WN = BN_ / 64, WM = NW / WN, TM = BIG_BM / WM / 16;  // waves along N / M, 16-row fragments per wave
-    constexpr int LA = BIG_BM / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
+    static_assert(BM_ == 256 || (BM_ == 128 && !TN && DG == 0 && !ROT && NW == 8), "128-row tiles: plain NT / NN forms");
+    constexpr int WN = BN_ / 64, WM = NW / WN, TM = BM_ / WM / 16;  // waves along N / M, 16-row fragments per wave
+    constexpr int LA = BM_ / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
     constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;                 // K-loop unroll: whole ring turns, even
     static_assert(NW == 8 || (NW == 4 && BN_ == 128), "4-wave blocks carry 256 x 128 tiles");
-    constexpr int ASLOTS = BIG_BM * 4, SLOTS = (BIG_BM + BN_) * 4;    // 16-byte slots per stage
+    constexpr int ASLOTS = BM_ * 4, SLOTS = (BM_ + BN_) * 4;          // 16-byte slots per stage
     constexpr int TMH = TM / 2;
     constexpr bool STAGED = sizeof(TO) == 2;                          // bf16 outputs leave through the staging region
     static_assert(NST >= 3 && NST <= 6, "ring depth");
@@ -523,7 +527,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     do {                                                                                                             \
         int tm_, tn_;                                                                                                \
         big_tile_map((int)(tile), ntiles, ntn, csplit, splitk > 1, tm_, tn_);                                        \
-        m0 = (int64_t)tm_ * BIG_BM;                                                                                  \
+        m0 = (int64_t)tm_ * BM_;                                                                                     \
         n0 = (int64_t)tn_ * BN_;                                                                                     \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                             \
             if constexpr (TA) { /* wave-instruction j = 2 token rows x 512 B */                                      \
@@ -689,7 +693,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         if (splitk > 1 && slabs) {
             // split-K partial tile: parked in the workspace in register order (every store a contiguous 1 KiB per wave);
             // splitk_reduce_kernel sums the slices and applies them to C
-            float4* dst = slabs + ((int64_t)(work / ntiles) * ntiles + tile) * (BIG_BM * BN_ / 4) + wave * TM * 4 * 64 + lane;
+            float4* dst = slabs + ((int64_t)(work / ntiles) * ntiles + tile) * (BM_ * BN_ / 4) + wave * TM * 4 * 64 + lane;
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -858,7 +862,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         // with a workspace (it rides in `slabs`, which split-K never uses here): this row tile's sums
                         // go to their own row of it and a fixed-order fold adds them up (bit-reproducible); else atomics
                         if (c < N) {
-                            if (slabs) reinterpret_cast<float*>(slabs)[(row_t / BIG_BM) * N + c] = t;
+                            if (slabs) reinterpret_cast<float*>(slabs)[(row_t / BM_) * N + c] = t;
                             else atomicAdd(colsum + c, t);
                         }
                     }
@@ -1393,9 +1397,15 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
             // rotary epilogue: the 128-wide tile has the registers to keep two passes of cos / sin rows in flight (the
             // 256-wide one spills with even one); same-box A/B at N = 2304: equal step time, so the narrow tile it is
             if (rot) wide = false;
+            // 128-row tiles when even the narrow 256-row tiles would fill at most half of the CUs (plain forward epilogues,
+            // bf16 out): twice the blocks, each with half the rows — the dual-track model's [2048 | 512, 1024] products
+            static const bool no_bm128 = getenv("SEDD_GEMM_NO_BM128") != nullptr;  // (A/B knob)
+            const bool bm128 = !no_bm128 && !dg && !rot && !accumulate && out_dtype == SEDD_BF16 &&
+                               epilogue != SEDD_EPI_BIAS_GELU_GRAD && M >= 128 && t128 * 2 <= cus;
+            if (bm128) wide = false;
             const int bn = wide ? 256 : 128;
             int64_t tn = (N + bn - 1) / bn;
-            const int64_t tiles = tm * tn;
+            const int64_t tiles = (bm128 ? (M + 127) / 128 : tm) * tn;
             int64_t kper = K;
             int splitk = 1;
             if (accumulate && out_dtype == SEDD_F32) big_splitk(tiles, K, &splitk, &kper);
@@ -1412,7 +1422,18 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
                        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue, (bf16_t*)pre,   \
                        accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,                                        \
                        (float4*)(DG_ == 1 || DG_ == 2 ? colsum_ws : nullptr), colsum, kNoRot)
-            if (rot) {
+            if (bm128) {
+                if (b_kn)
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, 0, 8, true, false, 128>), g2, dim3(512), 0,
+                                       st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
+                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
+                                       (float4*)nullptr, colsum, kNoRot);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, 0, 8, false, false, 128>), g2, dim3(512), 0,
+                                       st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
+                                       (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
+                                       (float4*)nullptr, colsum, kNoRot);
+            } else if (rot) {
                     hipLaunchKernelGGL((gemm_bf16_big_kernel<bf16_t, 128, 4, false, 0, 8, false, true>), g2, dim3(512), 0,
                                        st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, epilogue,
                                        (bf16_t*)pre, accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk,
