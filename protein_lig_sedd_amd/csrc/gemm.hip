@@ -1241,11 +1241,14 @@ static int choose_csplit(int64_t tm, int64_t tn, int64_t tiles, int64_t M, int64
 }
 
 // split-K plan for accumulating fp32 outputs with too few tiles for the 256 CUs: as many K slices as keep
-// tiles * slices <= 256 (one round of persistent blocks), every slice a whole number of K tiles, at least 16 of them
+// tiles * slices <= 256 (one round of persistent blocks), every slice a whole number of K tiles, at least 8 of them
 static void big_splitk(int64_t tiles, int64_t K, int* splitk, int64_t* kper) {
     const int64_t nkt = K / BIG_BK;
+    static const int min_kt = getenv("SEDD_SPLITK_MIN_KT") ? atoi(getenv("SEDD_SPLITK_MIN_KT")) : 8;  // K tiles per slice at least
+    // (A/B knob; 16 -> 8 in round 3: the dual-track model's weight gradients reduce over 2048 or 512 tokens only, cfg 3
+    // bf16 batch 4 38.1 -> 36.7 ms; 4 is slower again — slab traffic; cfg 2 / 4 reduce over >= 16 k tokens: not binding)
     int64_t sk = tiles > 0 ? cu_budget() / tiles : 1;
-    if (sk > nkt / 16) sk = nkt / 16;
+    if (sk > nkt / min_kt) sk = nkt / min_kt;
     if (sk < 1) sk = 1;
     const int64_t per = (nkt + sk - 1) / sk;
     *splitk = (int)((nkt + per - 1) / per);
