@@ -71,7 +71,8 @@ def test_bf16_training_reduces_loss():
 
 
 @pytest.mark.parametrize("cdt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("dims", [(768, 12, 512), (1024, 16, 1024)], ids=["cfg2_small_D768_H12_L512", "cfg4_large_D1024_H16_L1024"])
+@pytest.mark.parametrize("dims", [(768, 12, 512, 2), (1024, 16, 1024, 2), (768, 12, 512, 12)],
+                         ids=["cfg2_small_D768_H12_L512", "cfg4_large_D1024_H16_L1024", "cfg2_small_FULL_DEPTH_12_blocks"])
 def test_baseline_config_dims_match_the_oracle(dims, cdt, tol):
     """The dimensions of BASELINE configs[1] (SEDD small: D 768, 12 heads of 64, cond 128, L 512 — the bench workload) and
     configs[3] (large: D 1024, 16 heads of 64, L 1024), with 2 blocks and batch 2 to keep the CPU oracle quick: loss and
@@ -81,7 +82,7 @@ def test_baseline_config_dims_match_the_oracle(dims, cdt, tol):
     from protein_lig_sedd_amd import graph_lib, noise_lib
     from protein_lig_sedd_amd.losses import get_loss_fn
     from protein_lig_sedd_amd.model.transformer import _SEDD
-    (D, H, L), C, nb, tokens, B = dims, 128, 2, 25, 2
+    (D, H, L, nb), C, tokens, B = dims, 128, 25, 2   # (the third case is the bench model itself: all 12 blocks)
     torch.manual_seed(5)
     model = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
     sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=21)
@@ -99,12 +100,15 @@ def test_baseline_config_dims_match_the_oracle(dims, cdt, tol):
     with torch.no_grad():
         logits = model(xt.to(DEV), on(t)[0].to(DEV))
     assert rel_err(logits.float(), ref_logits.detach()) < tol, "logits"
-    for k in ("blocks.0.attn_qkv.weight", "blocks.1.mlp.2.weight", "blocks.0.adaLN_modulation.weight",
-              "blocks.1.norm2.weight", "output_layer.linear.weight", "vocab_embed.embedding.weight"):
+    last = nb - 1
+    for k in ("blocks.0.attn_qkv.weight", f"blocks.{last}.mlp.2.weight", "blocks.0.adaLN_modulation.weight",
+              f"blocks.{last}.norm2.weight", "output_layer.linear.weight", "vocab_embed.embedding.weight"):
         p = dict(model.named_parameters())[k]
         ref = sdr[k].grad
         err = float((p.grad.cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
-        assert err < (2e-4 if cdt == torch.float32 else 5e-2), f"{k}: relative gradient error {err:.3e}"
+        # (through 12 blocks the bf16 rounding of every block's activations accumulates in the early layers' gradients)
+        lim = 2e-4 if cdt == torch.float32 else (5e-2 if nb <= 2 else 1e-1)
+        assert err < lim, f"{k}: relative gradient error {err:.3e}"
 
 
 def _ref_style_state(model, noise, cfg):
