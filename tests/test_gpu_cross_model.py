@@ -389,3 +389,36 @@ def test_cross_trainer_hip_graph_matches_eager(golden):
     for name in ("p", "m", "v", "ema"):
         assert torch.equal(getattr(tg.flat, name), getattr(te.flat, name)), name
     assert_close(torch.tensor(oe[0][0]), g["losses"][0], 5e-4, 0)
+
+
+@pytest.mark.parametrize("cdt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_cfg3_full_depth_joint_forward_matches_the_oracle(cdt, tol):
+    """BASELINE configs[2] as `run_train_crossatt.sh` trains it — D 1024, 32 heads, cond 128, 12 + 12 blocks, Lp 512 + Ll 128,
+    batch 4 (528 M parameters) — `joint` logits and the as-written Q3 loss against oracle.cross_joint at FULL depth (forward
+    only, to keep the CPU oracle at a few seconds): fp32 as the reference computes (1e-4), and the bf16 compute path (2e-2)."""
+    from oracle import sedd_cpu as O
+    from protein_lig_sedd_amd.model.transformers_protlig_cross import ProteinLigandDiffusionModel
+    from protein_lig_sedd_amd import graph_lib
+    D, H, C, nb, B, Lp, Ll = 1024, 32, 128, 12, 4, 512, 128
+    sd = seeded_state_dict(cross_shapes(D, C, nb), seed=35, std=0.02)
+    model = ProteinLigandDiffusionModel(_cfg(D, H, C, nb), compute_dtype=cdt).to(DEV).eval()
+    load_sd(model, sd)
+    gen = torch.Generator().manual_seed(35)
+    p0 = torch.randint(0, 33, (B, Lp), generator=gen)
+    l0 = torch.randint(0, 2362, (B, Ll), generator=gen)
+    t = torch.rand(B, generator=gen) * 0.9 + 0.05
+    sigma, dsigma = O.make_noise("loglinear", eps=1e-3)(t)
+    gp_cpu, gl_cpu = O.AbsorbingCPU(36), O.AbsorbingCPU(2364)
+    pt = gp_cpu.sample_transition(p0, sigma[:, None], torch.rand(B, Lp, generator=gen))
+    lt = gl_cpu.sample_transition(l0, sigma[:, None], torch.rand(B, Ll, generator=gen))
+    with torch.no_grad():
+        rp, rl = O.cross_joint(sd, pt, lt, sigma, H, nb)
+        ref_loss = (dsigma[:, None] * ((gp_cpu.score_entropy(rp, sigma[:, None], pt, p0).mean()
+                                        + gl_cpu.score_entropy(rl, sigma[:, None], lt, l0).mean()) / 2)).mean()
+        ptd, ltd, p0d, l0d, sg, dsg = (z.to(DEV) for z in (pt, lt, p0, l0, sigma, dsigma))
+        lp, ll = model(protein_indices=ptd, ligand_indices=ltd, timesteps=sg, mode="joint")
+        assert rel_err(lp.float(), rp) < tol and rel_err(ll.float(), rl) < tol
+        gp, gl = graph_lib.Absorbing(36), graph_lib.Absorbing(2364)
+        loss = (dsg[:, None] * ((gp.score_entropy(lp, sg[:, None], ptd, p0d).mean()
+                                 + gl.score_entropy(ll, sg[:, None], ltd, l0d).mean()) / 2)).mean()
+    assert_close(loss, ref_loss, tol, 0, "Q3 loss")
