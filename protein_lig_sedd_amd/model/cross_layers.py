@@ -53,13 +53,21 @@ def part_fwd(x2d, W, b, r0, r1, out_dtype=None):
 
 def part_bwd(x2d, dy2d, W, b, r0, r1, gW, gb, need_dx=True, dx_dtype=None):
     """accumulate dW[r0:r1] += dy^T x, db[r0:r1] += colsum(dy); return dx = dy @ W[r0:r1] (or None)."""
-    if ops.gemm_tn_supported(dy2d, x2d):  # straight from the row-major activations
-        ops.gemm_tn(dy2d, x2d, out=gW[r0:r1], accumulate=True)
+    def wgrads():
+        if ops.gemm_tn_supported(dy2d, x2d):  # straight from the row-major activations
+            ops.gemm_tn(dy2d, x2d, out=gW[r0:r1], accumulate=True)
+        else:
+            align = 8 if dy2d.dtype == torch.bfloat16 else 4
+            ops.gemm_nt(transpose_padded(dy2d, align), transpose_padded(x2d, align), out=gW[r0:r1], accumulate=True)
+        if gb is not None:
+            ops.colsum(dy2d, out=gb[r0:r1], accumulate=True)
+
+    side = ops.SIDE
+    if side is not None and W.grad is not None and (b is None or gb is None or b.grad is not None):
+        with side.fork(x2d, dy2d):  # into the flat gradient buffer, read by the optimiser only: see layers.linear_bwd
+            wgrads()
     else:
-        align = 8 if dy2d.dtype == torch.bfloat16 else 4
-        ops.gemm_nt(transpose_padded(dy2d, align), transpose_padded(x2d, align), out=gW[r0:r1], accumulate=True)
-    if gb is not None:
-        ops.colsum(dy2d, out=gb[r0:r1], accumulate=True)
+        wgrads()
     if not need_dx:
         return None
     return part_dgrad(dy2d, W, r0, r1, dx_dtype=dx_dtype)

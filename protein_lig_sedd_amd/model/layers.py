@@ -63,8 +63,8 @@ def linear_fwd(x2d, W, bias=None, gelu=False, want_pre=False, out_dtype=None):
                        want_pre=want_pre, out_dtype=out_dtype)
 
 
-def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
-    """-> (dx [M, K] or None, dW for autograd or None, db for autograd or None)."""
+def _weight_grads(x2d, dy2d, W, bias):
+    """dW (+ db) of a Linear into the parameters' gradient sinks, or as fresh tensors: -> (dW or None, db or None)."""
     align = 8 if dy2d.dtype == torch.bfloat16 else 4
     sink = _sink(W)
     if ops.gemm_tn_supported(dy2d, x2d):  # dW = dY^T X straight from the row-major activations
@@ -88,6 +88,21 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
             ops.colsum(dy2d, out=bs, accumulate=True)
         else:
             db = ops.colsum(dy2d)
+    return dW, db
+
+
+def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
+    """-> (dx [M, K] or None, dW for autograd or None, db for autograd or None)."""
+    align = 8 if dy2d.dtype == torch.bfloat16 else 4
+    side = ops.SIDE
+    if side is not None and _sink(W) is not None and (bias is None or _sink(bias) is not None):
+        # the weight / bias gradients land in the flat gradient buffer, which only the optimiser reads: off the critical
+        # path of backward, so they go to the side stream (ops.SideStream) and the data gradient carries on here
+        with side.fork(x2d, dy2d):
+            _weight_grads(x2d, dy2d, W, bias)
+        dW = db = None
+    else:
+        dW, db = _weight_grads(x2d, dy2d, W, bias)
     dx = None
     if need_dx:
         Wc = compute_weight(W, dy2d.dtype)                        # [N, K] as stored

@@ -111,7 +111,7 @@ class SEDDTrainer:
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
                  process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False, accum=1,
-                 hip_graph=False, grad_comm_dtype=None, zero1=None):
+                 hip_graph=False, grad_comm_dtype=None, zero1=None, wgrad_stream=False):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
@@ -194,6 +194,9 @@ class SEDDTrainer:
         self.rank = dist.get_rank(process_group) if (self.dp and dist.is_initialized()) else 0
         per = self.flat.n // (self.world if self.zero1 else 1)
         self.shard = (self.rank * per, (self.rank + 1) * per) if self.zero1 else (0, self.flat.n)
+        # wgrad_stream=True (opt-in): weight- and bias-gradient launches of backward go to a second stream (ops.SideStream)
+        # and run beside the data-gradient chain; for steps whose kernels each fill a fraction of the chip (small batches)
+        self._side = ops.SideStream(self.flat.p.device) if (wgrad_stream and self.flat.p.is_cuda) else None
         self._gb = None  # bf16 staging buffer of the gradient exchange
         self._shards_dirty = False
         if self.zero1:
@@ -261,7 +264,7 @@ class SEDDTrainer:
                 self.model.train()
                 loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                                     mol_cond=mol_cond)
-                loss.backward()
+                self._backward(loss)
                 return (loss,)
 
             return self._graphed_step(body, inputs)[0]
@@ -271,14 +274,14 @@ class SEDDTrainer:
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                             mol_cond=mol_cond)
         if self.accum == 1:
-            loss.backward()
+            self._backward(loss)
             self.apply_gradients()
             return loss.detach()
         if self.overlap:
             raise RuntimeError("gradient accumulation with SEDD_DP_OVERLAP=1: the per-block buckets would all-reduce "
                                "every micro-step; use the default single all-reduce")
         loss = loss / self.accum
-        loss.backward()   # every backward kernel ACCUMULATES into the flat gradient buffer
+        self._backward(loss)   # every backward kernel ACCUMULATES into the flat gradient buffer
         self._accum_iter += 1
         self._accum_loss = loss.detach() if self._accum_loss is None else self._accum_loss + loss.detach()
         if self._accum_iter < self.accum:
@@ -401,6 +404,19 @@ class SEDDTrainer:
         """drop the captured steps (after anything a capture froze has changed: shapes are keyed, module structure,
         trainable set and hyper-parameters other than lr / step / EMA decay are not)."""
         self._graphs, self._graph_calls = {}, {}
+
+    def _backward(self, loss):
+        """loss.backward() with the weight-gradient launches on the side stream when one is configured; on return every
+        gradient launch is ordered before whatever the current stream does next."""
+        if self._side is None:
+            loss.backward()
+            return
+        ops.SIDE = self._side
+        try:
+            loss.backward()
+        finally:
+            ops.SIDE = None
+            self._side.join()
 
     def _reduce_gradients(self):
         """Finish the gradient all-reduce (SUM; the 1/world averaging is folded into the optimiser kernel's grad_scale):
@@ -633,14 +649,14 @@ class CrossAttTrainer(SEDDTrainer):
 
     def __init__(self, model, noise, graph_prot, graph_lig, optim, task="joint", ema_decay=0.9999, sampling_eps=1e-3,
                  world_size=None, process_group=None, lr_schedule=None, double_step=True, per_sample_weighting=False,
-                 hip_graph=False, grad_comm_dtype=None, zero1=None):
+                 hip_graph=False, grad_comm_dtype=None, zero1=None, wgrad_stream=False):
         if task in ("protein_given_ligand", "protein_only"):
             self.freeze_model(model, "lig")
         elif task in ("ligand_given_protein", "ligand_only"):
             self.freeze_model(model, "prot")
         super().__init__(model, noise, graph_prot, optim, ema_decay=ema_decay, sampling_eps=sampling_eps,
                          world_size=world_size, process_group=process_group, overlap=False, lr_schedule=lr_schedule,
-                         hip_graph=hip_graph, grad_comm_dtype=grad_comm_dtype, zero1=zero1)
+                         hip_graph=hip_graph, grad_comm_dtype=grad_comm_dtype, zero1=zero1, wgrad_stream=wgrad_stream)
         self._always_norm = True  # (this trainer reports the gradient norm whether or not it clips)
         self.graph_prot, self.graph_lig = graph_prot, graph_lig
         self.task, self.double_step, self.per_sample_weighting = task, double_step, per_sample_weighting
@@ -721,7 +737,7 @@ class CrossAttTrainer(SEDDTrainer):
             self.model.train()
             out = self.calc_loss(b, task, t=t, perturbed=pert)
             loss = out[0].mean() if task == "joint" else out.mean()
-            loss.backward()
+            self._backward(loss)
             if task == "joint":
                 return loss, out[1].mean(), out[2].mean()
             return (loss,)

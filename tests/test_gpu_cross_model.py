@@ -366,12 +366,12 @@ def test_cross_trainer_hip_graph_matches_eager(golden):
     D, H, C, nb = g["cfg"].tolist()
     b1, b2, eps, wd, clip, decay, wu, ms, blr, mlr, nlr = g["hyper"].tolist()
 
-    def run(hg):
+    def run(hg, side=False):
         model = ProteinLigandDiffusionModel(_cfg(D, H, C, nb), compute_dtype=torch.float32).to(DEV)
         load_sd(model, seeded_state_dict(cross_shapes(D, C, nb), seed=16, std=0.05))
         tr = CrossAttTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(DEV), graph_lib.Absorbing(36), graph_lib.Absorbing(2364),
                              dict(lr=3e-4, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, warmup=0, grad_clip=clip),
-                             task="joint", ema_decay=decay, world_size=1, hip_graph=hg,
+                             task="joint", ema_decay=decay, world_size=1, hip_graph=hg, wgrad_stream=side,
                              lr_schedule=lambda s: warmup_cosine_lr(s, int(wu), int(ms), blr, mlr, nlr))
         out = []
         for it in range(6):
@@ -384,6 +384,10 @@ def test_cross_trainer_hip_graph_matches_eager(golden):
 
     oe, te = run(False)
     og, tg = run(True)
+    # weight gradients on the side stream, eager and inside the captured graph (a forked capture): the same bits
+    for hg in (False, True):
+        os_, ts_ = run(hg, side=True)
+        assert os_ == oe and torch.equal(ts_.flat.p, te.flat.p) and torch.equal(ts_.flat.ema, te.flat.ema), hg
     assert og == oe
     assert tg.opt_steps == te.opt_steps == 12 and tg.ema.num_updates == 6
     for name in ("p", "m", "v", "ema"):

@@ -391,6 +391,13 @@ def test_hip_graph_train_step_is_bit_identical_to_eager(cdt):
 
     le, te = run(False)
     lg, tg = run(True)
+    # weight / bias gradients on a second stream (wgrad_stream=True): the same kernels in another interleaving, same bits
+    m2 = _SEDD(_cfg(D, H, C, nb, tokens), compute_dtype=cdt).to(DEV)
+    m2.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=False)
+    ts2 = SEDDTrainer(m2, noise, graph, dict(lr=1e-3, warmup=5, grad_clip=1.0, weight_decay=0.01), world_size=1, wgrad_stream=True)
+    ls = [float(ts2.train_step(xs[i], t=ts[i], u=us[i])) for i in range(steps)]
+    torch.cuda.synchronize()
+    assert ls == le and torch.equal(ts2.flat.p, te.flat.p) and torch.equal(ts2.flat.m, te.flat.m) and ts2._side.keep == []
     assert len(tg._graphs) == 1 and tg.step_count == steps and tg.ema.num_updates == steps
     assert lg == le
     for name in ("p", "m", "v", "ema"):
