@@ -24,7 +24,7 @@ for name in os.environ.get("CFG3_DTYPES", "fp32,bf16").split(","):
             if p.dim() >= 2: p.copy_(torch.randn(p.shape, device=dev, generator=g) * 0.02)
     tr = CrossAttTrainer(model, noise_lib.LogLinearNoise(eps=1e-3).to(dev), graph_lib.Absorbing(36), graph_lib.Absorbing(2364),
                          dict(lr=1e-4, warmup=1000, grad_clip=1.0), task="joint", ema_decay=0.9999, world_size=1,
-                         hip_graph=bool(os.environ.get("CFG3_GRAPH")), wgrad_stream=bool(os.environ.get("CFG3_SIDE")))
+                         hip_graph=bool(os.environ.get("CFG3_GRAPH")), wgrad_stream=os.environ.get("CFG3_SIDE", "1") == "1")
     bs = [dict(prot_tokens=torch.randint(0, 36, (B, Lp), device=dev), lig_tokens=torch.randint(0, 2364, (B, Ll), device=dev)) for _ in range(4)]
     for i in range(4): tr.train_step(bs[i % 4])
     torch.cuda.synchronize()
@@ -34,6 +34,6 @@ for name in os.environ.get("CFG3_DTYPES", "fp32,bf16").split(","):
     torch.cuda.synchronize()
     s = (time.perf_counter() - t0) / n
     P = sum(p.numel() for p in model.parameters())
-    print(f"cfg3 {name} batch {B}{' hip_graph' if os.environ.get('CFG3_GRAPH') else ''}{' wgrad_stream' if os.environ.get('CFG3_SIDE') else ''}: {s*1e3:.2f} ms/step, {B*(Lp+Ll)/s:.0f} tokens/s ({B/s:.1f} pairs/s), params {P/1e6:.1f} M, loss {float(out[0]):.4f}, host enqueue {host*1e3:.2f} ms/step", flush=True)
+    print(f"cfg3 {name} batch {B}{' hip_graph' if os.environ.get('CFG3_GRAPH') else ''}{' single-stream' if os.environ.get('CFG3_SIDE', '1') != '1' else ''}: {s*1e3:.2f} ms/step, {B*(Lp+Ll)/s:.0f} tokens/s ({B/s:.1f} pairs/s), params {P/1e6:.1f} M, loss {float(out[0]):.4f}, host enqueue {host*1e3:.2f} ms/step", flush=True)
     del tr, model
     torch.cuda.empty_cache()
