@@ -164,9 +164,9 @@ def cpu_baseline_cfg1(euler_steps_timed=12):
 
 
 # average HBM bytes per bf16 GEMM launch of this workload (B=64, L=512), measured with the PMC counters as the guide
-# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r2g_pmc_hbm_traffic.csv, last row (160 launches
+# prescribes (separate --pmc passes; FETCH_SIZE doubled on gfx950): profiles/r3f_pmc_hbm_traffic.csv, last row (160 launches
 # per step; 279.4e6 in r2_pmc_hbm_traffic.csv, when the family still held the 26 small adaLN-backward launches of a step)
-GEMM_HBM_BYTES_PER_LAUNCH = 324.3e6
+GEMM_HBM_BYTES_PER_LAUNCH = 322.7e6
 
 
 def gpu_cfg1(dev):
@@ -396,7 +396,7 @@ def main():
                                    "Linear fwd / dgrad / wgrad launch of the step",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": GEMM_HBM_BYTES_PER_LAUNCH if (B, L) == (64, 512) else None,
-                         "traffic_source": "profiles/r2g_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
+                         "traffic_source": "profiles/r3f_pmc_hbm_traffic.csv (2 x FETCH_SIZE + WRITE_SIZE, separate "
                                            "rocprofv3 --pmc passes of this command, average over the bf16 GEMM launches)",
                          "launches_per_step": n_g / max(args.steps, 1),
                          "timed_sample": "HIP events around every 5th launch of the family, scaled to all launches",
