@@ -339,6 +339,16 @@ int sedd_gemm_get_cu_budget(void);
 int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
                  int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
                  int64_t workspace_bytes, sedd_stream_t stream);
+/* The same weight gradient with the Linear's bias gradient out of the same launch (torch.nn.functional.linear's backward
+ * yields both; transformer.py:125-134, transformers_protlig_cross.py:250-268 — every nn.Linear there has a bias):
+ * colsum[M] (+)= sum over the tokens k of A[k, m], fp32, accumulated with C's `accumulate` flag.  bf16 operands, fp32 C
+ * only.  The sums come from one extra MFMA per 16-row fragment and K tile against a selector operand, dealt over the
+ * tile columns, in a fixed order (bit-reproducible).  With a split reduction the workspace needs
+ * slices * 256 * ceil(M / 256) * 4 bytes beyond sedd_gemm_tn's.  A reduction of at most 64 K tiles (2048 tokens) is not
+ * split: 128-wide tiles, one block per tile adding into C directly (one launch instead of three for dW and db). */
+int sedd_gemm_tn_colsum(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, void* colsum,
+                        int in_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
+                        int64_t workspace_bytes, sedd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ attention
  * The flash-attn boundary (transformer.py:172-183: flash_attn_varlen_qkvpacked_func, non-causal, no dropout,

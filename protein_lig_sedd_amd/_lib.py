@@ -57,6 +57,7 @@ SIGNATURES = {
     "sedd_gemm_nt": "plplpliipipilllp",
     "sedd_gemm_nt_ws": "plplpliipipilllplp",
     "sedd_gemm_tn": "plplpliiilllplp",
+    "sedd_gemm_tn_colsum": "plplplpiilllplp",
     "sedd_gemm_nt_dgelu": "plplpliippplllp",
     "sedd_gemm_nn": "plplpliipilllp",
     "sedd_gemm_nn_ws": "plplpliipilllplp",

@@ -463,6 +463,11 @@ extern "C" int sedd_debug_gemm_phase(uint64_t* host_dst) {
 // DG: 0 = forward epilogues, 1 = EPI_DGELU (pre-activation in, gelu' computed here), 2 = EPI_DMUL (multiplier in),
 //     3 = forward with SEDD_EPI_BIAS_GELU_GRAD (a kernel of its own: the 256-wide tiles sit at the register limit and a
 //     run-time choice between the two GELU epilogues spilled in every instantiation)
+//     4 = TN form that also emits the column sums of A over the reduction rows (the Linear's bias gradient next to its
+//     weight gradient: colsum[m] (+)= sum_k A[k, m]) — one more MFMA per handled 16-row fragment and K tile against a
+//     selector operand (row j of it all ones), so fragment j's sums land in column j of ONE extra accumulator; the
+//     fragments of a row tile are dealt over the tile columns and their waves (fragment m to column-wave m mod count),
+//     which keeps the extra matrix work to about one MFMA per wave and K tile
 // BM_: rows of the output tile — 256, or 128 (NT / NN forms with the plain forward epilogues only) for outputs whose
 //     256-row tiles would leave most of the chip idle (the dual-track model at batch 4: [2048, 1024] is 64 tiles of
 //     256 x 128 = a quarter of the CUs, [512, 1024] sixteen).
@@ -479,6 +484,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
     // ntn_cs = column tiles | (column split of the XCD map << 20), see big_tile_map / choose_csplit
     const int ntn = ntn_cs & 0xfffff, csplit = ntn_cs >> 20;
     static_assert(BM_ == 256 || (BM_ == 128 && !TN && DG == 0 && !ROT && NW == 8), "128-row tiles: plain NT / NN forms");
+    static_assert(DG != 4 || (TN && sizeof(TO) == 4 && NW == 8), "column sums ride on the fp32 weight-gradient form");
     constexpr int WN = BN_ / 64, WM = NW / WN, TM = BM_ / WM / 16;  // waves along N / M, 16-row fragments per wave
     constexpr int LA = BM_ / (NW * 16), LB = BN_ / (NW * 16), LPT = LA + LB;  // DMA wave-instructions per stage
     constexpr int UNR = NST % 2 == 0 ? NST : 2 * NST;                 // K-loop unroll: whole ring turns, even
@@ -612,6 +618,19 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         __builtin_amdgcn_s_setprio(0);                                                                               \
     } while (0)
 
+#define BIG_CS(asrc, mbase)                                                                                          \
+    do {                                                                                                             \
+        if constexpr (DG == 4) {                                                                                     \
+            _Pragma("unroll") for (int m = 0; m < TMH; ++m)                                                          \
+                if ((cs_mask >> ((mbase) + m)) & 1) {                                                                \
+                    union { uint32_t w[4]; bf16x8 v; } sel_;                                                         \
+                    const uint32_t one2_ = r15 == (mbase) + m ? 0x3F803F80u : 0u;                                    \
+                    sel_.w[0] = sel_.w[1] = sel_.w[2] = sel_.w[3] = one2_;                                           \
+                    cs_acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel_.v, asrc[m], cs_acc, 0, 0, 0);              \
+                }                                                                                                    \
+        }                                                                                                            \
+    } while (0)
+
 #ifdef GEMM_CLOCK_STAMP  // diagnostic build (tools/gemm_clock.py): shader clock held under load = d(memtime) / d(memrealtime) x 100 MHz
     const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -640,6 +659,15 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         // multiplies, the upper half is read; while the upper half multiplies, the next K tile's lower half and B
         // fragments are read (B is double-buffered, A's halves alternate) — 64 fragment registers instead of 96.
         bf16x8 a_lo[TMH], a_hi[TMH], b[2][4];
+        [[maybe_unused]] f32x4 cs_acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] int cs_mask = 0;
+        if constexpr (DG == 4) {
+            if (colsum) {
+                const int q = (int)(n0 / BN_) * WN + wn, nq = ntn * WN;  // this wave among the row tile's column-waves
+#pragma unroll
+                for (int m = 0; m < TM; ++m) cs_mask |= (m % nq == q) << m;
+            }
+        }
         // first K tile of this output tile: everything older (the previous tile's stores included) must have drained
         wait_tiles<LPT>(nkt - 1 < NST - 2 ? nkt - 1 : NST - 2);
         __builtin_amdgcn_s_barrier();
@@ -659,6 +687,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                 if (kt < nkt) {
                     BIG_READ_A(a_hi, s % NST, TMH);
                     BIG_MMA(a_lo, 0, s & 1);
+                    BIG_CS(a_lo, 0);
                     if (kt + 1 < nkt) {
                         const int rem = nkt - 2 - kt;
                         wait_tiles<LPT>(rem < NST - 3 ? rem : NST - 3);  // K tile kt+1 has landed (this wave's share)
@@ -675,6 +704,7 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
                         BIG_READ_B((s + 1) & 1, (s + 1) % NST);
                     }
                     BIG_MMA(a_hi, TMH, s & 1);
+                    BIG_CS(a_hi, TMH);
 #ifndef GEMM_NO_STAGGER
                     if (wave >= NW / 2 && kt + 1 < nkt && kt + NST - 1 < nkt) BIG_STAGE((s + NST - 1) % NST, kt + NST - 1);
 #endif
@@ -689,6 +719,23 @@ gemm_bf16_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
         if (next < ntiles) {
             BIG_TILE_SETUP(next);
             BIG_PROLOGUE();
+        }
+        if constexpr (DG == 4) {
+            if (cs_mask) {
+                // lane (i, g) holds, in element r, the sum of fragment 4g + r's row i
+                float* cs_slab = reinterpret_cast<float*>(slabs + (int64_t)splitk * ntiles * (BM_ * BN_ / 4));
+                const int64_t mpad = (int64_t)(ntiles / ntn) * BM_;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * (lane >> 4) + r;
+                    const int64_t row = row_t + m * 16 + (lane & 15);
+                    if (m < TM && ((cs_mask >> m) & 1) && row < M) {
+                        if (splitk > 1 && slabs) cs_slab[(int64_t)(work / ntiles) * mpad + row] = cs_acc[r];
+                        else if (splitk > 1) atomicAdd(colsum + row, cs_acc[r]);
+                        else colsum[row] = accumulate ? colsum[row] + cs_acc[r] : cs_acc[r];
+                    }
+                }
+            }
         }
         if (splitk > 1 && slabs) {
             // split-K partial tile: parked in the workspace in register order (every store a contiguous 1 KiB per wave);
@@ -1179,10 +1226,20 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(const float* __restrict__
 template <int BN_>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float4* __restrict__ slabs, float* __restrict__ C,
                                                             int64_t ldc, int64_t M, int64_t N, int ntn, int ntiles,
-                                                            int splitk, int accumulate) {
+                                                            int splitk, int accumulate, float* __restrict__ colsum) {
     constexpr int WN = BN_ / 64, WM = 8 / WN, TM = BIG_BM / WM / 16, PPT = BIG_BM * BN_ / 4;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)ntiles * PPT) return;
+    if (idx >= (int64_t)ntiles * PPT) {
+        // the column sums of A that rode along (DG = 4): one thread per row of C, the slices' partial sums lie behind
+        // the partial tiles
+        const int64_t row = idx - (int64_t)ntiles * PPT, mpad = (int64_t)(ntiles / ntn) * BIG_BM;
+        if (!colsum || row >= M) return;
+        const float* cs = reinterpret_cast<const float*>(slabs + (int64_t)splitk * ntiles * PPT);
+        float t = cs[row];
+        for (int k = 1; k < splitk; ++k) t += cs[(int64_t)k * mpad + row];
+        colsum[row] = accumulate ? colsum[row] + t : t;
+        return;
+    }
     const int tile = (int)(idx / PPT), pos = (int)(idx % PPT);
     float4 s = slabs[(int64_t)tile * PPT + pos];
     for (int k = 1; k < splitk; ++k) {
@@ -1642,11 +1699,15 @@ extern "C" int sedd_gemm_nn_dmul(const void* A, int64_t lda, const void* B, int6
 
 // C[M,N] (+)= A[K,M]^T * B[K,N]: weight gradient of nn.Linear straight from the row-major activations
 // (dW[out,in] = dY[tokens,out]^T X[tokens,in]), no transposed copies.  bf16 operands, fp32 or bf16 C.
-extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
-                            int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
-                            int64_t workspace_bytes, sedd_stream_t stream) {
+// colsum (optional; bf16 operands, fp32 C): colsum[M] (+)= sum_k A[k, m] out of the same launch — the Linear's bias
+// gradient next to its weight gradient (sedd_gemm_tn_colsum)
+static int gemm_tn_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                        int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
+                        int64_t workspace_bytes, float* colsum, sedd_stream_t stream) {
     SEDD_CHECK_ARG(out_dtype == SEDD_F32 || out_dtype == SEDD_BF16, "gemm_tn: bad dtype");
     SEDD_CHECK_ARG(M >= 0 && N >= 0 && K > 0, "gemm_tn: bad sizes M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    SEDD_CHECK_ARG(!colsum || (in_dtype == SEDD_BF16 && out_dtype == SEDD_F32),
+                   "gemm_tn_colsum: column sums ride on the bf16 -> fp32 form only");
     if (in_dtype == SEDD_F32) {  // exact-fp32 MFMA kernel, both operands read k-major as stored; any K
         if (out_dtype != SEDD_F32 || M % 4 || N % 4 || lda % 4 || ldb % 4 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
             lda < M || ldb < N || ldc < N) {
@@ -1675,7 +1736,14 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     const int64_t tm = (M + BIG_BM - 1) / BIG_BM;
     const int64_t t256 = tm * ((N + 255) / 256), t128 = tm * ((N + 127) / 128);
     // few, long tiles: prefer the tile width that leaves the finer split-K granularity
-    const bool wide = N > 128 && (t256 >= 128 || t128 > 256 || N % 256 == 0);
+    // A short reduction (the dual-track model at batch 4 reduces over 2048 or 512 tokens) is not split at all: 128-wide
+    // tiles, one block per tile walking all of K and adding into C directly.  The same GPU time as split + second pass at
+    // these sizes (1024 x 1024 over 2048 tokens: 17 + 10 us -> 27 us) and one launch fewer, which is what counts where
+    // the step is bound by the host's enqueue rate.  SEDD_TN_NOSPLIT_KT=0 restores the split.
+    static const int nosplit_kt = getenv("SEDD_TN_NOSPLIT_KT") ? atoi(getenv("SEDD_TN_NOSPLIT_KT")) : 64;
+    const bool nosplit = out_dtype == SEDD_F32 && K / BIG_BK <= nosplit_kt && t128 >= 16;
+    // (the 256-wide tile sits at 256 VGPRs: with the column sums' accumulator and selector it spills 71 -> 128-wide then)
+    const bool wide = !nosplit && !colsum && N > 128 && (t256 >= 128 || t128 > 256 || N % 256 == 0);
     const int bn = wide ? 256 : 128;
     const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
     SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_tn: too many tiles");
@@ -1685,37 +1753,54 @@ extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     // tiles there and a second pass sums them (any fp32 C); without one they add into C with fp32 atomics, which
     // needs an accumulating call (C already holds valid numbers) and is several times slower at 7+ adders per address.
     const bool can_split = out_dtype == SEDD_F32 && (accumulate || workspace);
-    if (can_split) big_splitk(tiles, K, &splitk, &kper);
+    if (can_split && !nosplit) big_splitk(tiles, K, &splitk, &kper);
     float4* slabs = nullptr;
     if (splitk > 1) {
-        const int64_t need = (int64_t)splitk * tiles * BIG_BM * bn * 4;
+        const int64_t need = (int64_t)splitk * tiles * BIG_BM * bn * 4 + (colsum ? (int64_t)splitk * tm * BIG_BM * 4 : 0);
         if (workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) slabs = (float4*)workspace;
         else if (!accumulate) { splitk = 1; kper = K; }
     }
     const dim3 g2((unsigned)(splitk > 1 ? tiles * splitk : (tiles < cu_budget() ? tiles : cu_budget())));
-#define TN_LAUNCH(TO, BN_)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, 0>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,        \
+#define TN_LAUNCH(TO, BN_, DG_)                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<TO, BN_, 4, true, DG_>), g2, dim3(512), 0, st, (const bf16_t*)A, lda,      \
                        (const bf16_t*)B, ldb, (TO*)C, ldc, (const float*)nullptr, (int)SEDD_EPI_NONE, (TO*)nullptr,  \
-                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, (float*)nullptr, kNoRot)
+                       accumulate, M, N, kper, K, (int)tn, (int)tiles, splitk, slabs, colsum, kNoRot)
     if (out_dtype == SEDD_BF16) {
-        if (wide) TN_LAUNCH(bf16_t, 256);
-        else TN_LAUNCH(bf16_t, 128);
+        if (wide) TN_LAUNCH(bf16_t, 256, 0);
+        else TN_LAUNCH(bf16_t, 128, 0);
+    } else if (colsum) {
+        TN_LAUNCH(float, 128, 4);
     } else {
-        if (wide) TN_LAUNCH(float, 256);
-        else TN_LAUNCH(float, 128);
+        if (wide) TN_LAUNCH(float, 256, 0);
+        else TN_LAUNCH(float, 128, 0);
     }
 #undef TN_LAUNCH
     SEDD_LAUNCH_CHECK();
     if (slabs) {
-        const int64_t n4 = tiles * BIG_BM * bn / 4;
-        const dim3 gr((unsigned)((n4 + 255) / 256));
+        const int64_t n4 = tiles * BIG_BM * bn / 4;  // (a multiple of 256: the column sums' threads start a new block)
+        const dim3 gr((unsigned)((n4 + (colsum ? tm * BIG_BM : 0) + 255) / 256));
         if (wide)
             hipLaunchKernelGGL((splitk_reduce_kernel<256>), gr, dim3(256), 0, st, (const float4*)slabs, (float*)C, ldc, M,
-                               N, (int)tn, (int)tiles, splitk, accumulate);
+                               N, (int)tn, (int)tiles, splitk, accumulate, colsum);
         else
             hipLaunchKernelGGL((splitk_reduce_kernel<128>), gr, dim3(256), 0, st, (const float4*)slabs, (float*)C, ldc, M,
-                               N, (int)tn, (int)tiles, splitk, accumulate);
+                               N, (int)tn, (int)tiles, splitk, accumulate, colsum);
         SEDD_LAUNCH_CHECK();
     }
     return SEDD_OK;
+}
+
+extern "C" int sedd_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int in_dtype,
+                            int out_dtype, int accumulate, int64_t M, int64_t N, int64_t K, void* workspace,
+                            int64_t workspace_bytes, sedd_stream_t stream) {
+    return gemm_tn_impl(A, lda, B, ldb, C, ldc, in_dtype, out_dtype, accumulate, M, N, K, workspace, workspace_bytes,
+                        nullptr, stream);
+}
+
+extern "C" int sedd_gemm_tn_colsum(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                   void* colsum, int in_dtype, int accumulate, int64_t M, int64_t N, int64_t K,
+                                   void* workspace, int64_t workspace_bytes, sedd_stream_t stream) {
+    SEDD_CHECK_ARG(colsum != nullptr, "gemm_tn_colsum: null colsum");
+    return gemm_tn_impl(A, lda, B, ldb, C, ldc, in_dtype, SEDD_F32, accumulate, M, N, K, workspace, workspace_bytes,
+                        (float*)colsum, stream);
 }

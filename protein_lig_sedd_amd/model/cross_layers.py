@@ -55,6 +55,9 @@ def part_bwd(x2d, dy2d, W, b, r0, r1, gW, gb, need_dx=True, dx_dtype=None):
     """accumulate dW[r0:r1] += dy^T x, db[r0:r1] += colsum(dy); return dx = dy @ W[r0:r1] (or None)."""
     def wgrads():
         if ops.gemm_tn_supported(dy2d, x2d):  # straight from the row-major activations
+            if gb is not None and dy2d.dtype == torch.bfloat16 and Lyr.TN_COLSUM:
+                ops.gemm_tn(dy2d, x2d, out=gW[r0:r1], accumulate=True, colsum=gb[r0:r1])  # db out of the same launch
+                return
             ops.gemm_tn(dy2d, x2d, out=gW[r0:r1], accumulate=True)
         else:
             align = 8 if dy2d.dtype == torch.bfloat16 else 4
@@ -64,8 +67,8 @@ def part_bwd(x2d, dy2d, W, b, r0, r1, gW, gb, need_dx=True, dx_dtype=None):
 
     side = ops.SIDE
     if side is not None and W.grad is not None and (b is None or gb is None or b.grad is not None):
-        with side.fork(x2d, dy2d):  # into the flat gradient buffer, read by the optimiser only: see layers.linear_bwd
-            wgrads()
+        # into the flat gradient buffer, read by the optimiser only: see layers.linear_bwd
+        side.defer(wgrads, x2d, dy2d, torch_ops=not ops.gemm_tn_supported(dy2d, x2d))
     else:
         wgrads()
     if not need_dx:

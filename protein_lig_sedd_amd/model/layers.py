@@ -52,6 +52,9 @@ def transpose_padded(a, align, out_dtype=None):
     return out
 
 
+TN_COLSUM = not os.environ.get("SEDD_NO_TN_COLSUM")  # A/B switch: bias gradients out of the weight-gradient launch
+
+
 def _sink(param):
     """(grad tensor to accumulate into or None, whether autograd should receive the result)."""
     return param.grad if (param is not None and param.grad is not None) else None
@@ -69,6 +72,10 @@ def _weight_grads(x2d, dy2d, W, bias):
     sink = _sink(W)
     if ops.gemm_tn_supported(dy2d, x2d):  # dW = dY^T X straight from the row-major activations
         if sink is not None:
+            bs = _sink(bias)
+            if bs is not None and dy2d.dtype == torch.bfloat16 and bs.is_contiguous() and TN_COLSUM:
+                ops.gemm_tn(dy2d, x2d, out=sink, accumulate=True, colsum=bs)  # db out of the same launch
+                return None, None
             ops.gemm_tn(dy2d, x2d, out=sink, accumulate=True)
             dW = None
         else:
@@ -98,8 +105,8 @@ def linear_bwd(x2d, dy2d, W, bias=None, need_dx=True, dx_dtype=None):
     if side is not None and _sink(W) is not None and (bias is None or _sink(bias) is not None):
         # the weight / bias gradients land in the flat gradient buffer, which only the optimiser reads: off the critical
         # path of backward, so they go to the side stream (ops.SideStream) and the data gradient carries on here
-        with side.fork(x2d, dy2d):
-            _weight_grads(x2d, dy2d, W, bias)
+        side.defer(lambda x=x2d, dy=dy2d: _weight_grads(x, dy, W, bias), x2d, dy2d,
+                   torch_ops=not ops.gemm_tn_supported(dy2d, x2d))  # (bound now: dy2d may be re-bound to a padded copy below)
         dW = db = None
     else:
         dW, db = _weight_grads(x2d, dy2d, W, bias)

@@ -85,9 +85,33 @@ _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 def _stream():
     """raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object
     through several Python layers — ~8 us a call, a fifth of the host time of a launch-bound step.)"""
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_STREAM_OVERRIDE = None  # raw handle every launch of this module goes to while a SideStream fork is open (see there)
+
+
+class _RawFork:
+    """`with` body: this module's launches go to the side stream.  torch's own current stream is left alone — entering
+    torch.cuda.stream() costs tens of microseconds, which 290 forks a step turned into the step's bottleneck — so the body
+    must launch through this module only and allocate nothing that is freed before join()."""
+    __slots__ = ("raw",)
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = self.raw
+
+    def __exit__(self, *exc):
+        global _STREAM_OVERRIDE
+        _STREAM_OVERRIDE = None
+        return False
 
 
 def _cuda(*ts):
@@ -109,16 +133,49 @@ class SideStream:
         self.stream = torch.cuda.Stream(device=device)
         self.keep = []
         self.dirty = False
+        self._events = [torch.cuda.Event() for _ in range(32)]  # re-recorded in turn: creating one per fork is slow
+        self._next = 0
+        self._raw = _RawFork(self.stream.cuda_stream)
+        self.pending = []
+        self.batch = int(os.environ.get("SEDD_SIDE_BATCH", "16"))
 
-    def fork(self, *tensors):
-        ev = torch.cuda.Event()
+    def fork(self, *tensors, torch_ops=False):
+        """torch_ops=True: the body also runs torch kernels or allocates temporaries (the slow torch.cuda.stream context);
+        otherwise only this module's launches move over."""
+        ev = self._events[self._next]
+        self._next = (self._next + 1) % len(self._events)
         ev.record()
         self.stream.wait_event(ev)
         self.keep.extend(t for t in tensors if t is not None)
         self.dirty = True
-        return torch.cuda.stream(self.stream)
+        return torch.cuda.stream(self.stream) if torch_ops else self._raw
+
+    def defer(self, fn, *tensors, torch_ops=False):
+        """queue `fn` for the side stream; the queue is flushed — ONE fork for all of it — every `batch` entries and at
+        join().  An event record + stream wait per weight gradient (290 a step in the dual-track model) cost more host
+        time than the launches themselves; the deferred launches lose nothing, they are off the critical path."""
+        self.pending.append((fn, torch_ops))
+        self.keep.extend(t for t in tensors if t is not None)
+        if len(self.pending) >= self.batch:
+            self.flush()
+
+    def flush(self):
+        global _STREAM_OVERRIDE
+        if not self.pending:
+            return
+        todo, self.pending = self.pending, []
+        with self.fork():
+            for fn, torch_ops in todo:
+                if torch_ops:
+                    _STREAM_OVERRIDE = None
+                    with torch.cuda.stream(self.stream):
+                        fn()
+                    _STREAM_OVERRIDE = self._raw.raw
+                else:
+                    fn()
 
     def join(self):
+        self.flush()
         if self.dirty:
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
             self.dirty = False
@@ -827,9 +884,10 @@ def _tn_workspace(device):
     return _scratch("splitk", device, 256 * 256 * 256)
 
 
-def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):
+def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False, colsum=None):
     """C[M,N] (+)= A[K,M]^T @ B[K,N] (weight gradient: A = dY [tokens, out], B = X [tokens, in]); bf16 or fp32
-    operands (fp32: fp32 C only)."""
+    operands (fp32: fp32 C only).  colsum (bf16 operands, fp32 C): fp32 [M] that receives (+)= the column sums of A —
+    the bias gradient — from the same launch, under the same `accumulate` flag as C."""
     K, M = A.shape
     K2, N = B.shape
     if K != K2 or A.dtype != B.dtype:
@@ -838,6 +896,15 @@ def gemm_tn(A, B, out=None, out_dtype=None, accumulate=False):
         out = torch.empty(M, N, dtype=out_dtype or torch.float32, device=A.device)
         accumulate = False
     ws = _tn_workspace(A.device) if out.dtype == torch.float32 else None
+    if colsum is not None:
+        if (A.dtype != torch.bfloat16 or out.dtype != torch.float32 or colsum.dtype != torch.float32
+                or colsum.numel() != M or not colsum.is_contiguous()):
+            raise ValueError("gemm_tn: colsum needs bf16 operands, an fp32 C and a contiguous fp32 [M]")
+        with _Timed("gemm_bf16_nt", 2.0 * M * N * K):
+            check(lib().sedd_gemm_tn_colsum(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _p(colsum),
+                                            _dt(A), 1 if accumulate else 0, M, N, K, _p(ws), ws.numel() * 4, _stream()),
+                  "sedd_gemm_tn_colsum")
+        return out
     with _Timed("gemm_bf16_nt" if A.dtype == torch.bfloat16 else "gemm_f32_nt", 2.0 * M * N * K):
         check(lib().sedd_gemm_tn(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), _dt(A), _dt(out),
                                  1 if accumulate else 0, M, N, K, _p(ws), 0 if ws is None else ws.numel() * 4,

@@ -129,6 +129,36 @@ def test_gemm_tn_bf16(K, M, N):
     assert not ops.gemm_tn_supported(A[:31], B[:31])
 
 
+@pytest.mark.parametrize("K,M,N", [(512, 1024, 1024), (2048, 3072, 1024), (2048, 1024, 4096), (4096, 1024, 1024),
+                                   (32768, 768, 3072), (96, 264, 136), (2048, 128, 1024), (8192, 40, 72)])
+def test_gemm_tn_colsum(K, M, N):
+    """weight gradient with the bias gradient (column sums of dY) out of the same launch: unsplit short reductions,
+    split ones (partial sums behind the partial tiles), ragged edges, accumulate on and off, repeatable bit for bit."""
+    ops = _ops()
+    torch.manual_seed(K + M + N)
+    A = torch.randn(K, M, device=DEV).bfloat16()
+    B = torch.randn(K, N, device=DEV).bfloat16()
+    ref, cref = A.double().T @ B.double(), A.double().sum(0)
+    cs = torch.full((M,), 7.0, device=DEV)
+    C = ops.gemm_tn(A, B, colsum=cs)                       # fresh C: both are overwritten
+    assert rel_err(C, ref) < 1e-5 and rel_err(cs, cref) < 1e-5
+    C1 = torch.randn(M, N, device=DEV)
+    c1 = torch.randn(M, device=DEV)
+    C0, c0 = C1.clone(), c1.clone()
+    ops.gemm_tn(A, B, out=C1, accumulate=True, colsum=c1)
+    assert rel_err(C1, C0.double() + ref) < 1e-5 and rel_err(c1, c0.double() + cref) < 1e-5
+    C2, c2 = C0.clone(), c0.clone()
+    ops.gemm_tn(A, B, out=C2, accumulate=True, colsum=c2)
+    assert torch.equal(C1, C2) and torch.equal(c1, c2)
+    # the product itself is the one the plain entry point gives when both take the same tiles (unsplit / 128-wide)
+    wa = torch.randn(K, M + 64, device=DEV).bfloat16()
+    c3 = torch.zeros(M, device=DEV)
+    ops.gemm_tn(wa[:, 32:32 + M], B, out=torch.zeros(M, N, device=DEV), accumulate=True, colsum=c3)
+    assert rel_err(c3, wa[:, 32:32 + M].double().sum(0)) < 1e-5
+    with pytest.raises(ValueError):
+        ops.gemm_tn(A.float(), B.float(), colsum=cs)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 3072, 768), (300, 200, 96)])
 def test_gemm_nt_dgelu(M, N, K):
     """fused data gradient through GELU + bias-gradient column sums == gemm -> gelu_bwd -> colsum."""

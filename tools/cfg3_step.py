@@ -29,7 +29,22 @@ for name in os.environ.get("CFG3_DTYPES", "fp32,bf16").split(","):
     for i in range(4): tr.train_step(bs[i % 4])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(n): out = tr.train_step(bs[i % 4])
+    if os.environ.get("CFG3_CPROFILE"):  # where the host's enqueue time goes (the step is host-bound at batch 4)
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for i in range(n): out = tr.train_step(bs[i % 4])
+        pr.disable()
+        st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45); st.sort_stats("cumulative").print_stats(60)
+    elif os.environ.get("CFG3_SYNC_EACH"):  # every step starts on an idle GPU: host time of one step without back-pressure
+        hs, ts = [], []
+        for i in range(n):
+            torch.cuda.synchronize(); a0 = time.perf_counter()
+            out = tr.train_step(bs[i % 4]); a1 = time.perf_counter()
+            torch.cuda.synchronize(); a2 = time.perf_counter()
+            hs.append(a1 - a0); ts.append(a2 - a0)
+        print(f"  per-step with a sync between steps: host enqueue {1e3*sum(hs)/n:.2f} ms, step {1e3*sum(ts)/n:.2f} ms", flush=True)
+    else:
+        for i in range(n): out = tr.train_step(bs[i % 4])
     host = (time.perf_counter() - t0) / n  # time to ENQUEUE a step: ~ the step time when the host is the limiter
     torch.cuda.synchronize()
     s = (time.perf_counter() - t0) / n
