@@ -45,6 +45,19 @@ class GradSink:
         return {n: self.fresh.get(n) for n in names}
 
 
+_ONES = {}
+
+
+def _ones(B, D, device):
+    """the all-ones [B, D] gate of the cross-attention residual (x + dropout(x_ca)): read-only, one per shape and device
+    instead of a fill launch per block and step."""
+    key = (B, D, device)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(B, D, dtype=torch.float32, device=device)
+    return t
+
+
 def part_fwd(x2d, W, b, r0, r1, out_dtype=None):
     """rows [r0, r1) of a packed projection: x2d @ W[r0:r1]^T + b[r0:r1]"""
     return ops.gemm_nt(x2d, compute_weight(W, x2d.dtype)[r0:r1], bias=None if b is None else b.detach()[r0:r1],
@@ -133,7 +146,7 @@ def cross_block_forward(x, c, other, other_mask, P, n_heads, cos, sin, p_drop, c
         xc = Lyr.linear_fwd(co.view(M, D), P["cross_attn.cross_attn.out_proj.weight"],
                             P["cross_attn.cross_attn.out_proj.bias"], out_dtype=torch.float32).view(B, L, D)
         keepc = Lyr.dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
-        ones = torch.ones(B, D, dtype=torch.float32, device=x.device)
+        ones = _ones(B, D, x.device)
         xm = ops.gate_residual_fwd(x1, xc, ones, keepc, inv)  # x + dropout(x_ca): gate == 1
         if save:
             st["ca"] = dict(xn=xn, meanc=meanc, rstdc=rstdc, ctx=ctx, cq=cq, ckv=ckv, km=km, co=co, clse=clse, xc=xc,
@@ -179,8 +192,7 @@ def cross_block_backward(dx2, st, P, n_heads):
         Lo = ca["Lo"]
         Wc, bc = P["cross_attn.cross_attn.in_proj_weight"], P["cross_attn.cross_attn.in_proj_bias"]
         gWc, gbc = G("cross_attn.cross_attn.in_proj_weight"), G("cross_attn.cross_attn.in_proj_bias")
-        dgate_unused = torch.empty(B, D, dtype=torch.float32, device=x.device)
-        dxc = ops.gate_residual_bwd(dx, ca["xc"], ca["ones"], dgate_unused, ca["keepc"], st["inv"]).view(M, D)
+        dxc = ops.gate_residual_bwd(dx, ca["xc"], ca["ones"], None, ca["keepc"], st["inv"]).view(M, D)
         dxc_c = dxc if cdt == torch.float32 else ops.cast(dxc, cdt)
         dco = part_bwd(ca["co"].view(M, D), dxc_c, P["cross_attn.cross_attn.out_proj.weight"],
                        P["cross_attn.cross_attn.out_proj.bias"], 0, D, G("cross_attn.cross_attn.out_proj.weight"),

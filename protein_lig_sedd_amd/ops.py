@@ -625,8 +625,11 @@ def gate_residual_bwd(dout, a, gate, dgate, keep=None, inv_keep=1.0, dbias=None)
     kp, seed, pd = _keep_args(keep)
     check(lib().sedd_gate_residual_bwd(_p(dout), _p(a), _dt(a), _p(g), mdt, ms, kp, float(inv_keep), seed, pd, _p(da),
                                        _p(ws), 0 if dbias is None else 1, M, L, D, _stream()), "sedd_gate_residual_bwd")
-    check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), _p(dbias), M, L, D, _stream()),
-          "sedd_gate_residual_bwd_reduce")
+    if dgate is not None:  # (None: the gate is a constant — the cross-attention residual's all-ones gate — and has no gradient)
+        check(lib().sedd_gate_residual_bwd_reduce(_p(ws), _p(dgate), dgate.stride(0), _p(dbias), M, L, D, _stream()),
+              "sedd_gate_residual_bwd_reduce")
+    elif dbias is not None:
+        raise ValueError("gate_residual_bwd: dbias rides on the gate gradient's fold")
     return da
 
 
