@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SEDD_ABI_VERSION 5
+#define SEDD_ABI_VERSION 6
 
 typedef void* sedd_stream_t; /* hipStream_t */
 
@@ -159,6 +159,15 @@ int sedd_ln_modulate_bwd_gate(const void* dy, int dy_dtype, const float* x, cons
                               const float* dx_add, float* ws, const void* a, const void* gate, float inv_keep,
                               uint64_t seed, float p_drop, void* da, float* ws_gate, int64_t M, int64_t L, int D,
                               sedd_stream_t stream);
+/* The same at a block BOUNDARY (transformer.py:188-189 feeding the next block's :166 norm1): the gated residual is the
+ * previous block's MLP branch, so the column sums of da as stored — mlp[2]'s bias gradient, sedd_gate_residual_bwd's
+ * want_colsum — ride along: ws_gate is fp32 [2, nchunk, D] (gate-gradient partials, then bias-gradient partials), folded
+ * by sedd_gate_residual_bwd_reduce(ws_gate, dgate, stride, dbias, ...). */
+int sedd_ln_modulate_bwd_gate_colsum(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
+                                     int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
+                                     const float* dx_add, float* ws, const void* a, const void* gate, float inv_keep,
+                                     uint64_t seed, float p_drop, void* da, float* ws_gate, int64_t M, int64_t L, int D,
+                                     sedd_stream_t stream);
 int sedd_ln_modulate_bwd(const void* dy, int dy_dtype, const float* x, const float* w, const void* scale,
                          int mod_dtype, int64_t mod_stride, const float* mean, const float* rstd, float* dx,
                          const float* dx_add, float* ws, int64_t M, int64_t L, int D, sedd_stream_t stream);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sedd_ln_modulate_fwd": "pppppilpippllip",
     "sedd_ln_modulate_bwd": "pipppilpppppllip",
     "sedd_ln_modulate_bwd_gate": "pipppilppppp" + "pp" + "flf" + "pp" + "llip",
+    "sedd_ln_modulate_bwd_gate_colsum": "pipppilppppp" + "pp" + "flf" + "pp" + "llip",
     "sedd_ln_modulate_bwd_reduce": "ppppl" + "llip",
     "sedd_ln_modulate_bwd_noalloc": "pipppilpppp" + "pppl" + "llip",
     "sedd_gate_residual_fwd": "ppipilpflfpllip",

@@ -167,9 +167,11 @@ extern "C" int64_t sedd_ln_bwd_chunks(int64_t M, int64_t L) {
 // GATE: the finished dx row additionally goes through the backward of the gated residual that FEEDS this LayerNorm
 // (x = residual + gate_b * dropout(a), fused_add_dropout_scale.py:13-48): da = dx * gate_b * keep (dtype of dy) and
 // the per-chunk partials of dgate = sum_l dx * a * keep go to ws_gate — what gate_res_bwd_kernel would compute from a
-// second pass over dx.
+// second pass over dx.  ws_bias (optional): per-chunk column sums of da AS STORED (the bias gradient of the Linear that
+// produced a), gate_res_bwd_kernel's ws2.
 struct GateBwdArgs {
     const void* a; const void* gate; void* da; float* ws_gate; float inv_keep; uint64_t seed; uint32_t thr16;
+    float* ws_bias;
 };
 template <typename TD, typename TM, int NV, bool GATE>
 __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ dy, const float* __restrict__ x,
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
     const int64_t chunk = blockIdx.x, b = chunk / cpb, c0 = (chunk % cpb) * CR;
     const int nrows = (int)((L - c0) < CR ? (L - c0) : CR);
     float4 ww[NV], sc1[NV], aw[NV], ash[NV], asc[NV];
-    float4 gt[GATE ? NV : 1], agt[GATE ? NV : 1];
+    float4 gt[GATE ? NV : 1], agt[GATE ? NV : 1], abs_[GATE ? NV : 1];
     const TD* ga_a = reinterpret_cast<const TD*>(ga.a);
     TD* ga_da = reinterpret_cast<TD*>(ga.da);
 #pragma unroll
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
         const int c = k * 256 + lane * 4;
         if constexpr (GATE) {
             gt[k] = c < D ? load4<TM>(reinterpret_cast<const TM*>(ga.gate) + b * mod_stride + c) : f4(0.f);
-            agt[k] = f4(0.f);
+            agt[k] = abs_[k] = f4(0.f);
         }
         ww[k] = c < D ? load4<float>(w + c) : f4(0.f);
         float4 s = f4(0.f);
@@ -256,8 +258,13 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
                 if constexpr (GATE) {
                     float4 kk = f4(1.f);
                     if (ga.thr16) kk = keep4_hashed(ga.seed, row * D + c, ga.thr16, ga.inv_keep);
-                    store4<TD>(ga_da + row * D + c, make_float4(o.x * gt[k].x * kk.x, o.y * gt[k].y * kk.y,
-                                                                 o.z * gt[k].z * kk.z, o.w * gt[k].w * kk.w));
+                    const float4 dav = make_float4(o.x * gt[k].x * kk.x, o.y * gt[k].y * kk.y, o.z * gt[k].z * kk.z,
+                                                   o.w * gt[k].w * kk.w);
+                    store4<TD>(ga_da + row * D + c, dav);
+                    if (ga.ws_bias) {
+                        const float4 rr = round4<TD>(dav);
+                        abs_[k].x += rr.x; abs_[k].y += rr.y; abs_[k].z += rr.z; abs_[k].w += rr.w;
+                    }
                     agt[k].x += o.x * gA[k].x * kk.x; agt[k].y += o.y * gA[k].y * kk.y;
                     agt[k].z += o.z * gA[k].z * kk.z; agt[k].w += o.w * gA[k].w * kk.w;
                 }
@@ -319,6 +326,27 @@ __global__ void __launch_bounds__(TPB) ln_mod_bwd_kernel(const TD* __restrict__ 
             const int c = i * 4;
             if (c < D) store4<float>(ga.ws_gate + chunk * D + c, load4<float>(red + c));
         }
+        if (ga.ws_bias) {  // (block-uniform) the same fold for the column sums of da
+            __syncthreads();
+            for (int wv = 0; wv < TPB / 64; ++wv) {
+                if (wave == wv) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        float* r0 = red + k * 256 + lane * 4;
+                        if (wv == 0) store4<float>(r0, abs_[k]);
+                        else {
+                            const float4 p = load4<float>(r0);
+                            store4<float>(r0, make_float4(p.x + abs_[k].x, p.y + abs_[k].y, p.z + abs_[k].z, p.w + abs_[k].w));
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            for (int i = threadIdx.x; i < NV * 64; i += TPB) {
+                const int c = i * 4;
+                if (c < D) store4<float>(ga.ws_bias + chunk * D + c, load4<float>(red + c));
+            }
+        }
     }
 }
 
@@ -337,7 +365,7 @@ static int ln_modulate_bwd_impl(const char* nm, const void* dy, int dy_dtype, co
     SEDD_CHECK_ARG(!ga || (ga->a && ga->gate && ga->da && ga->ws_gate), "%s: null pointer", nm);
     const int64_t nchunk = sedd_ln_bwd_chunks(M, L);
     hipStream_t st = (hipStream_t)stream;
-    const GateBwdArgs g0 = ga ? *ga : GateBwdArgs{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0};
+    const GateBwdArgs g0 = ga ? *ga : GateBwdArgs{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 0, nullptr};
 #define LN_BWD_LAUNCH(NV_, G_)                                                                                        \
     hipLaunchKernelGGL((ln_mod_bwd_kernel<TD, TM, NV_, G_>), dim3((unsigned)nchunk), dim3(TPB), 0, st, (const TD*)dy, x, \
                        w, (const TM*)scale, mod_stride, mean, rstd, dx, dx_add, ws, nchunk, L, D, chunk_rows(M), g0)
@@ -371,9 +399,27 @@ extern "C" int sedd_ln_modulate_bwd_gate(const void* dy, int dy_dtype, const flo
                                          float inv_keep, uint64_t seed, float p_drop, void* da, float* ws_gate,
                                          int64_t M, int64_t L, int D, sedd_stream_t stream) {
     SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_modulate_bwd_gate: p_drop %f", (double)p_drop);
-    const GateBwdArgs ga{a, gate, da, ws_gate, inv_keep, seed, (uint32_t)(p_drop * 65536.0f + 0.5f)};
+    const GateBwdArgs ga{a, gate, da, ws_gate, inv_keep, seed, (uint32_t)(p_drop * 65536.0f + 0.5f), nullptr};
     return ln_modulate_bwd_impl("ln_modulate_bwd_gate", dy, dy_dtype, x, w, scale, mod_dtype, mod_stride, mean, rstd, dx,
                                 dx_add, ws, M, L, D, &ga, stream);
+}
+
+// ... and with the column sums of da as stored (sedd_gate_residual_bwd's want_colsum): ws_gate then holds TWO planes of
+// [nchunk, D] — the gate-gradient partials and the bias-gradient partials — exactly what sedd_gate_residual_bwd_reduce
+// folds.  This is the form a block BOUNDARY takes: the LayerNorm is the next block's norm1, the gated residual the
+// previous block's MLP branch, whose second Linear's bias gradient is the column sum.
+extern "C" int sedd_ln_modulate_bwd_gate_colsum(const void* dy, int dy_dtype, const float* x, const float* w,
+                                                const void* scale, int mod_dtype, int64_t mod_stride, const float* mean,
+                                                const float* rstd, float* dx, const float* dx_add, float* ws,
+                                                const void* a, const void* gate, float inv_keep, uint64_t seed,
+                                                float p_drop, void* da, float* ws_gate, int64_t M, int64_t L, int D,
+                                                sedd_stream_t stream) {
+    SEDD_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ln_modulate_bwd_gate_colsum: p_drop %f", (double)p_drop);
+    SEDD_CHECK_ARG(ws_gate != nullptr, "ln_modulate_bwd_gate_colsum: null pointer");
+    const GateBwdArgs ga{a, gate, da, ws_gate, inv_keep, seed, (uint32_t)(p_drop * 65536.0f + 0.5f),
+                         ws_gate + sedd_ln_bwd_chunks(M, L) * D};
+    return ln_modulate_bwd_impl("ln_modulate_bwd_gate_colsum", dy, dy_dtype, x, w, scale, mod_dtype, mod_stride, mean, rstd,
+                                dx, dx_add, ws, M, L, D, &ga, stream);
 }
 
 // out_k[b, j] = sum over the chunks of batch b of plane k (blocks [0, nxb * B));  planes in vec_mask are instead summed

@@ -193,19 +193,48 @@ def dropout_mask(shape, p, device):
 
 
 # ------------------------------------------------------------------------------------------------- DDiT block
+class BlockLink:
+    """What two CONSECUTIVE DDiT blocks share so that the passes over the residual stream at their boundary fuse
+    (transformer.py:188-189 of block i feeding :165-166 of block i+1): forward — block i's last gated residual and block
+    i+1's first LayerNorm-modulate are one kernel (sedd_gate_residual_ln_modulate_fwd: x2 is written once and not re-read),
+    for which block i evaluates block i+1's adaLN projection and hands over (mod, h1, mean1, rstd1); backward — block i+1's
+    norm1 backward and block i's gated-residual backward (with mlp[2]'s bias gradient) are one kernel
+    (sedd_ln_modulate_bwd_gate_colsum) and block i+1 hands back (dy, dmod with the gate slice filled, a fresh bias gradient
+    when the parameter has no gradient sink).  Built by _SEDD._forward only: there x2 has exactly one consumer, which is
+    what lets block i+1's dx stand in for autograd's gradient of x2.  A block that finds its link empty runs stand-alone."""
+    __slots__ = ("norm1_w", "ada_w", "ada_b", "mlp2_bias", "mod", "h1", "mean1", "rstd1", "prev", "dy", "dmod_prev",
+                 "db2_fresh")
+
+    def __init__(self, prev_block, next_block):
+        self.norm1_w, self.ada_w, self.ada_b = (next_block.norm1.weight, next_block.adaLN_modulation.weight,
+                                                 next_block.adaLN_modulation.bias)
+        self.mlp2_bias = prev_block.mlp[2].bias
+        self.mod = self.h1 = self.mean1 = self.rstd1 = self.prev = self.dy = self.dmod_prev = self.db2_fresh = None
+
+
+BLOCK_CHAIN = not os.environ.get("SEDD_NO_BLOCK_CHAIN")  # A/B switch for the boundary fusion
+
+
 BLOCK_PARAMS = ("norm1.weight", "attn_qkv.weight", "attn_out.weight", "norm2.weight", "mlp.0.weight", "mlp.0.bias",
                 "mlp.2.weight", "mlp.2.bias", "adaLN_modulation.weight", "adaLN_modulation.bias")
 
 
-def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens=None):
+def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens=None, link_in=None, link_out=None):
     """DDiTBlock.forward (model/transformer.py:153-189).  x fp32 [B, L, D]; c fp32 [B, C]; P: dict of the block's
-    parameters by reference name; cos/sin compact rotary tables.  Returns x_out fp32 and (if save) the saved state."""
+    parameters by reference name; cos/sin compact rotary tables.  Returns x_out fp32 and (if save) the saved state.
+    link_in / link_out: BlockLink with the previous / next block (None: stand-alone)."""
     B, L, D = x.shape
     M, H, d = B * L, n_heads, D // n_heads
-    c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
-    mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 6D]
+    chained_in = link_in is not None and link_in.h1 is not None
+    c_c = None
     w1, w2 = P["norm1.weight"].detach(), P["norm2.weight"].detach()
-    h1, mean1, rstd1 = ops.ln_modulate_fwd(x, w1, shift=mod[:, :D], scale=mod[:, D:2 * D], out_dtype=cdt)
+    if chained_in:  # the previous block's last pass already produced this block's modulation and LayerNorm-modulate
+        mod, h1, mean1, rstd1 = link_in.mod, link_in.h1, link_in.mean1, link_in.rstd1
+        link_in.mod = link_in.h1 = link_in.mean1 = link_in.rstd1 = None
+    else:
+        c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+        mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 6D]
+        h1, mean1, rstd1 = ops.ln_modulate_fwd(x, w1, shift=mod[:, :D], scale=mod[:, D:2 * D], out_dtype=cdt)
     Wqkv = compute_weight(P["attn_qkv.weight"], cdt)
     if ops.gemm_nt_rotary_supported(h1.view(M, D), Wqkv, L, H, d):  # rotary rides in the projection's epilogue
         qkv = ops.gemm_nt_rotary(h1.view(M, D), Wqkv, cos, sin, L, H, d).view(B, L, 3, H, d)
@@ -235,12 +264,23 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
         g, u = linear_fwd(h2.view(M, D), P["mlp.0.weight"], P["mlp.0.bias"], gelu=True), None
     y = linear_fwd(g, P["mlp.2.weight"], P["mlp.2.bias"]).view(B, L, D)
     keep2 = dropout_mask((B, L, D), p_drop, x.device) if p_drop > 0 else None
-    x2 = ops.gate_residual_fwd(x1, y, mod[:, 5 * D:6 * D], keep2, inv)
+    chained_out = link_out is not None and ops.gate_residual_ln_modulate_supported(x1, y, keep2)
+    if chained_out:  # x2 and the NEXT block's LayerNorm-modulate of it in one pass over the rows
+        if c_c is None:
+            c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+        mod_n = linear_fwd(c_c, link_out.ada_w, link_out.ada_b)
+        x2, link_out.h1, link_out.mean1, link_out.rstd1 = ops.gate_residual_ln_modulate_fwd(
+            x1, y, mod[:, 5 * D:6 * D], keep2, inv, link_out.norm1_w.detach(), mod_n[:, :D], mod_n[:, D:2 * D])
+        link_out.mod = mod_n
+        link_out.prev = dict(y=y, gate=mod[:, 5 * D:6 * D], keep2=keep2, inv=inv) if save else None
+    else:
+        x2 = ops.gate_residual_fwd(x1, y, mod[:, 5 * D:6 * D], keep2, inv)
     st = None
     if save:
         st = dict(x=x, c=c, mod=mod, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, a=a, keep1=keep1,
                   x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, u=u, u_grad=u_grad, g=g, y=y, keep2=keep2, inv=inv, cos=cos,
-                  sin=sin, cu=cu_seqlens)
+                  sin=sin, cu=cu_seqlens, link_in=link_in if chained_in else None,
+                  link_out=link_out if chained_out else None)
     return x2, st
 
 
@@ -251,12 +291,18 @@ def ddit_block_backward(dx2, st, P, n_heads):
     M, H, d = B * L, n_heads, D // n_heads
     mod, cdt = st["mod"], st["h1"].dtype
     grads = {}
-    dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(dx2)  # = dx2 + both LN-branch gradients (dx2 itself is autograd's and stays untouched)
     # ---- MLP branch: x2 = x1 + gate_mlp * dropout(mlp(modulate(LN(x1))))
-    db2, grads["mlp.2.bias"] = _vec_sink(P["mlp.2.bias"], D)  # column sums of dy ride along in the same pass
-    dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"],
-                               dbias=db2).view(M, D)
+    lo = st.get("link_out")
+    if lo is not None and lo.dy is not None:
+        # the next block's norm1 backward already sent its finished dx (= dx2) through this gated residual's backward
+        dy, dmod, grads["mlp.2.bias"] = lo.dy.view(M, D), lo.dmod_prev, lo.db2_fresh
+        lo.dy = lo.dmod_prev = lo.db2_fresh = lo.prev = None
+    else:
+        dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
+        db2, grads["mlp.2.bias"] = _vec_sink(P["mlp.2.bias"], D)  # column sums of dy ride along in the same pass
+        dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"],
+                                   dbias=db2).view(M, D)
     du, grads["mlp.2.weight"], _, grads["mlp.0.bias"] = mlp_out_bwd(
         st["g"], st["u"], dy, P["mlp.2.weight"], None, P["mlp.0.bias"], u_is_grad=st["u_grad"])
     dh2, grads["mlp.0.weight"], _ = linear_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], None)
@@ -284,8 +330,19 @@ def ddit_block_backward(dx2, st, P, n_heads):
         ops.rotary_qkv_(dqkv, st["cos"], st["sin"], conj=True)  # positions are row positions: not fused into the stores
     dh1, grads["attn_qkv.weight"], _ = linear_bwd(st["h1"].view(M, D), dqkv.view(M, 3 * D), P["attn_qkv.weight"])
     dw1, grads["norm1.weight"] = _vec_sink(P["norm1.weight"], D)
-    ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],
-                        dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D])
+    li = st.get("link_in")
+    if li is not None and li.prev is not None and dh1.dtype == li.prev["y"].dtype:
+        # block boundary: norm1's backward and the PREVIOUS block's last gated residual's backward (with its mlp[2] bias
+        # gradient) share one pass over the rows of the finished dx
+        pv = li.prev
+        li.dmod_prev = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
+        db2p, li.db2_fresh = _vec_sink(li.mlp2_bias, D)
+        li.dy = ops.ln_modulate_bwd_gate(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"],
+                                         st["rstd1"], dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D], pv["y"], pv["gate"],
+                                         li.dmod_prev[:, 5 * D:6 * D], pv["keep2"], pv["inv"], dbias=db2p)
+    else:
+        ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],
+                            dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D])
     # ---- adaLN: mod = Linear(c)
     # fp32 operands whatever the compute dtype: dmod [B, 6D] and c [B, C] are fp32 as they stand and a batch is a few dozen
     # rows, so the exact-fp32 kernels take them as stored (weight gradient from [B, .] row-major, dc against the master

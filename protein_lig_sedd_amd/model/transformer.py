@@ -116,11 +116,11 @@ class EmbeddingLayer(nn.Module):
 
 class _DDiTBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, blk, cos, sin, save, cu, *params):
+    def forward(ctx, x, c, blk, cos, sin, save, cu, links, *params):
         P = dict(zip(Lyr.BLOCK_PARAMS, params))
         p = blk.dropout if blk.training else 0.0
         out, st = Lyr.ddit_block_forward(x.contiguous(), c.contiguous(), P, blk.n_heads, cos, sin, p, blk.compute_dtype, save,
-                                         cu_seqlens=cu)
+                                         cu_seqlens=cu, link_in=links[0], link_out=links[1])
         ctx.st, ctx.P, ctx.n_heads, ctx.blk = st, P, blk.n_heads, blk
         return out
 
@@ -131,7 +131,7 @@ class _DDiTBlockFn(torch.autograd.Function):
         cb = getattr(ctx.blk, "_on_grads_ready", None)  # trainer hook: this block's gradient bucket is complete
         if cb is not None:
             cb()
-        return (dx, dc, None, None, None, None, None) + _ret(grads, Lyr.BLOCK_PARAMS)
+        return (dx, dc, None, None, None, None, None, None) + _ret(grads, Lyr.BLOCK_PARAMS)
 
 
 class DDiTBlock(nn.Module):
@@ -167,7 +167,7 @@ class DDiTBlock(nn.Module):
             self._rot = (key,) + Lyr.compact_rotary(cos, sin)
         return self._rot[1], self._rot[2]
 
-    def forward(self, x, rotary_cos_sin, c, seqlens=None):
+    def forward(self, x, rotary_cos_sin, c, seqlens=None, _links=(None, None)):
         """seqlens (transformer.py:173-179): the flash-attn varlen hook — `cu_seqlens = seqlens.cumsum(-1)` cuts the
         flattened (batch x sequence) token axis into segments and attention runs inside each segment (variable-length
         packing); as in the reference the caller's `seqlens` therefore starts with 0 and sums to batch x seq_len, and the
@@ -175,7 +175,8 @@ class DDiTBlock(nn.Module):
         cos, sin = self._tables(rotary_cos_sin)
         P = _params(self, Lyr.BLOCK_PARAMS)
         cu = None if seqlens is None else seqlens.cumsum(-1).to(torch.int32).contiguous()
-        return _DDiTBlockFn.apply(x, c, self, cos, sin, torch.is_grad_enabled(), cu, *[P[n] for n in Lyr.BLOCK_PARAMS])
+        return _DDiTBlockFn.apply(x, c, self, cos, sin, torch.is_grad_enabled(), cu, _links if cu is None else (None, None),
+                                  *[P[n] for n in Lyr.BLOCK_PARAMS])
 
 
 class _FinalLayerFn(torch.autograd.Function):
@@ -278,8 +279,12 @@ class _SEDD(nn.Module):
         x = self.vocab_embed(indices)
         c = self._cond(sigma, esm_cond, mol_cond)
         rotary_cos_sin = self.rotary_emb(x)
-        for blk in self.blocks:
-            x = blk(x, rotary_cos_sin, c, seqlens=None)
+        # consecutive blocks share a BlockLink: the residual-stream passes at their boundary run fused (layers.BlockLink)
+        n = len(self.blocks)
+        links = [Lyr.BlockLink(self.blocks[i], self.blocks[i + 1]) for i in range(n - 1)] if Lyr.BLOCK_CHAIN else []
+        for i, blk in enumerate(self.blocks):
+            lk = (links[i - 1] if links and i > 0 else None, links[i] if links and i < n - 1 else None)
+            x = blk(x, rotary_cos_sin, c, seqlens=None, _links=lk)
         x = self.output_layer(x, c)
         if self.scale_by_sigma:
             assert self.absorb, "Haven't configured this to work."

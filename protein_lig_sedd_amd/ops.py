@@ -511,9 +511,11 @@ def ln_modulate_bwd(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dsc
           "sedd_ln_modulate_bwd_reduce")
 
 
-def ln_modulate_bwd_gate(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dscale, a, gate, dgate, keep, inv_keep):
-    """ln_modulate_bwd + gate_residual_bwd(dx, a, gate, dgate, keep, inv_keep) in one pass over the rows -> da.
-    (x = residual + gate * dropout(a) is the gated residual that feeds this LayerNorm; keep: DropSeed or None.)"""
+def ln_modulate_bwd_gate(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift, dscale, a, gate, dgate, keep, inv_keep,
+                         dbias=None):
+    """ln_modulate_bwd + gate_residual_bwd(dx, a, gate, dgate, keep, inv_keep[, dbias]) in one pass over the rows -> da.
+    (x = residual + gate * dropout(a) is the gated residual that feeds this LayerNorm; keep: DropSeed or None;
+    dbias fp32 [D] (optional) += da.sum over rows, as gate_residual_bwd's.)"""
     add = dx if accumulate is True else (None if (accumulate is False or accumulate is None) else accumulate)
     if add is not None and (add.shape != dx.shape or add.dtype != torch.float32 or not add.is_contiguous()):
         raise ValueError("ln_modulate_bwd_gate: addend must be a contiguous fp32 tensor of dx's shape")
@@ -522,21 +524,21 @@ def ln_modulate_bwd_gate(dy, x, w, scale, mean, rstd, dx, accumulate, dw, dshift
     B, L, D = x.shape
     M = B * L
     nchunk = lib().sedd_ln_bwd_chunks(M, L)
-    ws = torch.empty(4 * nchunk * D, dtype=torch.float32, device=x.device)
+    ws = torch.empty((5 if dbias is not None else 4) * nchunk * D, dtype=torch.float32, device=x.device)
     wsg = ws[3 * nchunk * D:]
     sc, mdt, ms = _mod_args(scale)
     g, gdt, gs = _mod_args(gate)
     if (gdt, gs) != (mdt, ms):
-        raise ValueError("scale and gate must be slices of one modulation tensor")
+        raise ValueError("scale and gate must be slices of modulation tensors of one dtype and row stride")
     _, seed, pd = _keep_args(keep)
     da = torch.empty_like(a)
-    check(lib().sedd_ln_modulate_bwd_gate(_p(dy), _dt(dy), _p(x), _p(w), _p(sc), mdt, ms, _p(mean), _p(rstd), _p(dx),
-                                          _p(add), _p(ws), _p(a), _p(g), float(inv_keep), seed, pd, _p(da), _p(wsg), M, L,
-                                          D, _stream()), "sedd_ln_modulate_bwd_gate")
+    fn = lib().sedd_ln_modulate_bwd_gate if dbias is None else lib().sedd_ln_modulate_bwd_gate_colsum
+    check(fn(_p(dy), _dt(dy), _p(x), _p(w), _p(sc), mdt, ms, _p(mean), _p(rstd), _p(dx), _p(add), _p(ws), _p(a), _p(g),
+             float(inv_keep), seed, pd, _p(da), _p(wsg), M, L, D, _stream()), "sedd_ln_modulate_bwd_gate")
     dstride = dshift.stride(0) if dshift is not None else (dscale.stride(0) if dscale is not None else D)
     check(lib().sedd_ln_modulate_bwd_reduce(_p(ws), _p(dw), _p(dshift), _p(dscale), dstride, M, L, D, _stream()),
           "sedd_ln_modulate_bwd_reduce")
-    check(lib().sedd_gate_residual_bwd_reduce(_p(wsg), _p(dgate), dgate.stride(0), None, M, L, D, _stream()),
+    check(lib().sedd_gate_residual_bwd_reduce(_p(wsg), _p(dgate), dgate.stride(0), _p(dbias), M, L, D, _stream()),
           "sedd_gate_residual_bwd_reduce")
     return da
 

@@ -48,7 +48,7 @@ def test_header_symbols_exported_and_signatures_match():
         assert _lib.SIGNATURES[name] == sig, f"{name}: ctypes '{_lib.SIGNATURES[name]}' vs header '{sig}'"
     for name in _lib.SIGNATURES:
         assert name in protos, f"{name} bound in _lib.py but not declared in the header"
-    assert L.sedd_abi_version() == 5
+    assert L.sedd_abi_version() == 6
 
 
 def test_argument_validation_without_gpu():

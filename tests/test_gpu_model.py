@@ -158,6 +158,53 @@ def test_sedd_model_bf16_vs_oracle():
     assert rel_err(out.float(), ref32) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sinks", [False, True])
+def test_block_boundary_fusion_matches_stand_alone_blocks(dtype, sinks):
+    """_SEDD chains consecutive blocks (layers.BlockLink): block i's last gated residual + block i+1's first LayerNorm in
+    one pass, their backwards in one pass.  Against the same model with the chain switched off: the forward is the same
+    bits (dropout on), every gradient agrees to fp32 fold-order noise; with and without gradient sinks on the
+    parameters; eval-mode (sampling) forward bit-identical too."""
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.model import layers as Lyr
+    from protein_lig_sedd_amd import ops
+    D, H, C, nb, tokens, B, L = 128, 2, 64, 3, 25, 3, 48
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=51, std=0.05)
+    torch.manual_seed(5)
+    xt = torch.randint(0, tokens + 1, (B, L), device=DEV)
+    sigma = torch.rand(B, device=DEV) * 3 + 0.1
+    wgt = torch.randn(B, L, tokens + 1, device=DEV)
+
+    def run(chain, train=True):
+        cfg = sedd_config(D, H, C, nb, tokens)
+        cfg.model.dropout = 0.1
+        model = _SEDD(cfg, compute_dtype=dtype).to(DEV)
+        load_sd(model, sd)
+        model.train(train)
+        if sinks:
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+        Lyr.BLOCK_CHAIN = chain
+        ops.DropSeed._counter = 0
+        try:
+            if not train:
+                with torch.no_grad():
+                    return model(xt, sigma), None
+            out = model(xt, sigma)
+            (out.float() * wgt).sum().backward()
+        finally:
+            Lyr.BLOCK_CHAIN = True
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert torch.equal(o1, o0)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-5, k
+    assert torch.equal(g1["blocks.1.attn_qkv.weight"], g0["blocks.1.attn_qkv.weight"])  # (the data path is the same bits)
+    assert torch.equal(run(True, train=False)[0], run(False, train=False)[0])
+
+
 def test_kat_init_loss():
     """SURVEY section 4 KAT: with the reference's zero-init the logits are -log(e^sigma-1) - log(V-1) and the loss
     per masked token log(V-1)/(e^sigma-1)."""

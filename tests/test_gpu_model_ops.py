@@ -399,6 +399,15 @@ def test_ln_modulate_bwd_gate_fused_matches_the_two_kernels(B, L, D, dtype, p):
     assert torch.equal(dm2[:, 3 * D:5 * D], dm1[:, 3 * D:5 * D])
     assert rel_err(dw2, dw1) < 1e-5                                   # (atomic adds over the batch: order varies)
     assert rel_err(dm2[:, 2 * D:3 * D], dm1[:, 2 * D:3 * D]) < 1e-5   # (rows fold in another order than gate_res_bwd's)
+    # block-boundary form: the column sums of da as stored (the producing Linear's bias gradient) ride along
+    db1, db3 = torch.full((D,), 0.5, device=DEV), torch.full((D,), 0.5, device=DEV)
+    ops.gate_residual_bwd(dx1, a, mod[:, 2 * D:3 * D], dm1[:, 2 * D:3 * D], keep, inv, dbias=db1)
+    dx3, dw3, dm3 = torch.empty_like(x), torch.zeros(D, device=DEV), torch.zeros(B, 6 * D, device=DEV)
+    da3 = ops.ln_modulate_bwd_gate(dy, x, w, mod[:, 4 * D:5 * D], mean, rstd, dx3, add, dw3, dm3[:, 3 * D:4 * D],
+                                   dm3[:, 4 * D:5 * D], a, mod[:, 2 * D:3 * D], dm3[:, 2 * D:3 * D], keep, inv, dbias=db3)
+    assert torch.equal(dx3, dx1) and torch.equal(da3, da1) and torch.equal(dm3, dm2) and torch.equal(dw3, dw2)
+    assert rel_err(db3, db1) < 1e-5
+    assert rel_err(db3 - 0.5, da1.double().sum((0, 1))) < (1e-5 if dtype == torch.float32 else 1e-4)
 
 
 @pytest.mark.parametrize("d", [32, 64, 96])
