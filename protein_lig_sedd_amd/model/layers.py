@@ -206,8 +206,10 @@ class BlockLink:
                  "db2_fresh")
 
     def __init__(self, prev_block, next_block):
-        self.norm1_w, self.ada_w, self.ada_b = (next_block.norm1.weight, next_block.adaLN_modulation.weight,
-                                                 next_block.adaLN_modulation.bias)
+        # next_block: a DDiTBlock, or the DDitFinalLayer behind the last block (its LayerNorm is `norm_final` and its
+        # modulation [B, 2D]; the block lays that into a [B, 6D]-strided buffer so that one row stride serves the kernel)
+        norm = next_block.norm1 if hasattr(next_block, "norm1") else next_block.norm_final
+        self.norm1_w, self.ada_w, self.ada_b = norm.weight, next_block.adaLN_modulation.weight, next_block.adaLN_modulation.bias
         self.mlp2_bias = prev_block.mlp[2].bias
         self.mod = self.h1 = self.mean1 = self.rstd1 = self.prev = self.dy = self.dmod_prev = self.db2_fresh = None
 
@@ -268,7 +270,11 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
     if chained_out:  # x2 and the NEXT block's LayerNorm-modulate of it in one pass over the rows
         if c_c is None:
             c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
-        mod_n = linear_fwd(c_c, link_out.ada_w, link_out.ada_b)
+        if link_out.ada_w.shape[0] == 6 * D:
+            mod_n = linear_fwd(c_c, link_out.ada_w, link_out.ada_b)
+        else:  # the final layer's [B, 2D] modulation, at this block's row stride
+            mod_n = torch.empty(B, 6 * D, dtype=cdt, device=x.device)[:, :link_out.ada_w.shape[0]]
+            ops.gemm_nt(c_c, compute_weight(link_out.ada_w, cdt), bias=link_out.ada_b.detach(), out=mod_n)
         x2, link_out.h1, link_out.mean1, link_out.rstd1 = ops.gate_residual_ln_modulate_fwd(
             x1, y, mod[:, 5 * D:6 * D], keep2, inv, link_out.norm1_w.detach(), mod_n[:, :D], mod_n[:, D:2 * D])
         link_out.mod = mod_n
@@ -356,16 +362,22 @@ def ddit_block_backward(dx2, st, P, n_heads):
 FINAL_PARAMS = ("norm_final.weight", "linear.weight", "linear.bias", "adaLN_modulation.weight", "adaLN_modulation.bias")
 
 
-def final_layer_forward(x, c, P, cdt, save):
-    """DDitFinalLayer.forward (model/transformer.py:234-238) -> logits [B, L, V] in the compute dtype."""
+def final_layer_forward(x, c, P, cdt, save, link_in=None):
+    """DDitFinalLayer.forward (model/transformer.py:234-238) -> logits [B, L, V] in the compute dtype.
+    link_in: BlockLink with the last block (the LayerNorm-modulate then came out of that block's last pass)."""
     B, L, D = x.shape
     M = B * L
-    c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
-    mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 2D]
-    h, mean, rstd = ops.ln_modulate_fwd(x, P["norm_final.weight"].detach(), shift=mod[:, :D], scale=mod[:, D:2 * D],
-                                        out_dtype=cdt)
+    chained = link_in is not None and link_in.h1 is not None
+    if chained:
+        mod, h, mean, rstd = link_in.mod, link_in.h1, link_in.mean1, link_in.rstd1
+        link_in.mod = link_in.h1 = link_in.mean1 = link_in.rstd1 = None
+    else:
+        c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+        mod = linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])            # [B, 2D]
+        h, mean, rstd = ops.ln_modulate_fwd(x, P["norm_final.weight"].detach(), shift=mod[:, :D], scale=mod[:, D:2 * D],
+                                            out_dtype=cdt)
     logits = linear_fwd(h.view(M, D), P["linear.weight"], P["linear.bias"]).view(B, L, -1)
-    st = dict(x=x, c=c, mod=mod, h=h, mean=mean, rstd=rstd) if save else None
+    st = dict(x=x, c=c, mod=mod, h=h, mean=mean, rstd=rstd, link_in=link_in if chained else None) if save else None
     return logits, st
 
 
@@ -382,8 +394,17 @@ def final_layer_backward(dlogits, st, P):
     dmod = torch.empty(B, 2 * D, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     dw, grads["norm_final.weight"] = _vec_sink(P["norm_final.weight"], D)
-    ops.ln_modulate_bwd(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"], st["rstd"], dx,
-                        False, dw, dmod[:, :D], dmod[:, D:2 * D])
+    li = st.get("link_in")
+    if li is not None and li.prev is not None and dh.dtype == li.prev["y"].dtype:  # block boundary: see ddit_block_backward
+        pv = li.prev
+        li.dmod_prev = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
+        db2p, li.db2_fresh = _vec_sink(li.mlp2_bias, D)
+        li.dy = ops.ln_modulate_bwd_gate(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"],
+                                         st["rstd"], dx, False, dw, dmod[:, :D], dmod[:, D:2 * D], pv["y"], pv["gate"],
+                                         li.dmod_prev[:, 5 * D:6 * D], pv["keep2"], pv["inv"], dbias=db2p)
+    else:
+        ops.ln_modulate_bwd(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"], st["rstd"],
+                            dx, False, dw, dmod[:, :D], dmod[:, D:2 * D])
     # fp32 operands whatever the compute dtype: dmod [B, 6D] and c [B, C] are fp32 as they stand and a batch is a few dozen
     # rows, so the exact-fp32 kernels take them as stored (weight gradient from [B, .] row-major, dc against the master
     # weight with K split over blocks) — the bf16 route needed a cast, a transposed weight copy and a zero-fill per block

@@ -181,9 +181,9 @@ class DDiTBlock(nn.Module):
 
 class _FinalLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, c, lyr, save, *params):
+    def forward(ctx, x, c, lyr, save, link, *params):
         P = dict(zip(Lyr.FINAL_PARAMS, params))
-        out, st = Lyr.final_layer_forward(x.contiguous(), c.contiguous(), P, lyr.compute_dtype, save)
+        out, st = Lyr.final_layer_forward(x.contiguous(), c.contiguous(), P, lyr.compute_dtype, save, link_in=link)
         ctx.st, ctx.P = st, P
         return out
 
@@ -191,7 +191,7 @@ class _FinalLayerFn(torch.autograd.Function):
     def backward(ctx, dout):
         dx, dc, grads = Lyr.final_layer_backward(dout.contiguous(), ctx.st, ctx.P)
         ctx.st = None
-        return (dx, dc, None, None) + _ret(grads, Lyr.FINAL_PARAMS)
+        return (dx, dc, None, None, None) + _ret(grads, Lyr.FINAL_PARAMS)
 
 
 class DDitFinalLayer(nn.Module):
@@ -208,9 +208,9 @@ class DDitFinalLayer(nn.Module):
         self.adaLN_modulation.bias.data.zero_()
         self.compute_dtype = compute_dtype
 
-    def forward(self, x, c):
+    def forward(self, x, c, _link=None):
         P = _params(self, Lyr.FINAL_PARAMS)
-        return _FinalLayerFn.apply(x, c, self, torch.is_grad_enabled(), *[P[n] for n in Lyr.FINAL_PARAMS])
+        return _FinalLayerFn.apply(x, c, self, torch.is_grad_enabled(), _link, *[P[n] for n in Lyr.FINAL_PARAMS])
 
 
 class _EpilogueFn(torch.autograd.Function):
@@ -281,11 +281,11 @@ class _SEDD(nn.Module):
         rotary_cos_sin = self.rotary_emb(x)
         # consecutive blocks share a BlockLink: the residual-stream passes at their boundary run fused (layers.BlockLink)
         n = len(self.blocks)
-        links = [Lyr.BlockLink(self.blocks[i], self.blocks[i + 1]) for i in range(n - 1)] if Lyr.BLOCK_CHAIN else []
+        nxt = list(self.blocks[1:]) + [self.output_layer]
+        links = [Lyr.BlockLink(self.blocks[i], nxt[i]) for i in range(n)] if Lyr.BLOCK_CHAIN else [None] * n
         for i, blk in enumerate(self.blocks):
-            lk = (links[i - 1] if links and i > 0 else None, links[i] if links and i < n - 1 else None)
-            x = blk(x, rotary_cos_sin, c, seqlens=None, _links=lk)
-        x = self.output_layer(x, c)
+            x = blk(x, rotary_cos_sin, c, seqlens=None, _links=(links[i - 1] if i > 0 else None, links[i]))
+        x = self.output_layer(x, c, _link=links[n - 1] if n else None)
         if self.scale_by_sigma:
             assert self.absorb, "Haven't configured this to work."
         return _EpilogueFn.apply(x, sigma, indices, bool(self.scale_by_sigma))
