@@ -201,9 +201,13 @@ class BlockLink:
     norm1 backward and block i's gated-residual backward (with mlp[2]'s bias gradient) are one kernel
     (sedd_ln_modulate_bwd_gate_colsum) and block i+1 hands back (dy, dmod with the gate slice filled, a fresh bias gradient
     when the parameter has no gradient sink).  Built by _SEDD._forward only: there x2 has exactly one consumer, which is
-    what lets block i+1's dx stand in for autograd's gradient of x2.  A block that finds its link empty runs stand-alone."""
+    what lets block i+1's dx stand in for autograd's gradient of x2.  A block that finds its link empty runs stand-alone.
+    Guards: the next block takes the hand-over only if its input IS the x2 the link was filled for (a forward hook that
+    replaces a block's output breaks the chain silently and correctly); in backward, the gradient autograd delivers for x2
+    must be the very dx the next block returned — a second consumer of x2 (an activation hook feeding the loss) makes
+    autograd sum into another tensor, which is detected and refused (SEDD_NO_BLOCK_CHAIN=1 then)."""
     __slots__ = ("norm1_w", "ada_w", "ada_b", "mlp2_bias", "mod", "h1", "mean1", "rstd1", "prev", "dy", "dmod_prev",
-                 "db2_fresh")
+                 "db2_fresh", "x2_key", "dx_key")
 
     def __init__(self, prev_block, next_block):
         # next_block: a DDiTBlock, or the DDitFinalLayer behind the last block (its LayerNorm is `norm_final` and its
@@ -211,7 +215,26 @@ class BlockLink:
         norm = next_block.norm1 if hasattr(next_block, "norm1") else next_block.norm_final
         self.norm1_w, self.ada_w, self.ada_b = norm.weight, next_block.adaLN_modulation.weight, next_block.adaLN_modulation.bias
         self.mlp2_bias = prev_block.mlp[2].bias
+        self.x2_key = self.dx_key = None
         self.mod = self.h1 = self.mean1 = self.rstd1 = self.prev = self.dy = self.dmod_prev = self.db2_fresh = None
+
+    @staticmethod
+    def key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape))
+
+    def taken_by(self, x):
+        """whether the hand-over was made for exactly this input tensor (else it is dropped)."""
+        if self.h1 is None:
+            return False
+        if self.x2_key != BlockLink.key(x):
+            self.mod = self.h1 = self.mean1 = self.rstd1 = self.prev = None
+            return False
+        return True
+
+    def check_grad(self, dx2):
+        if self.dx_key != BlockLink.key(dx2):
+            raise RuntimeError("block-boundary fusion: the output of a DDiT block has a second consumer (the gradient "
+                               "autograd delivers is not the next block's dx); run with SEDD_NO_BLOCK_CHAIN=1")
 
 
 BLOCK_CHAIN = not os.environ.get("SEDD_NO_BLOCK_CHAIN")  # A/B switch for the boundary fusion
@@ -227,7 +250,7 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
     link_in / link_out: BlockLink with the previous / next block (None: stand-alone)."""
     B, L, D = x.shape
     M, H, d = B * L, n_heads, D // n_heads
-    chained_in = link_in is not None and link_in.h1 is not None
+    chained_in = link_in is not None and link_in.taken_by(x)
     c_c = None
     w1, w2 = P["norm1.weight"].detach(), P["norm2.weight"].detach()
     if chained_in:  # the previous block's last pass already produced this block's modulation and LayerNorm-modulate
@@ -277,7 +300,7 @@ def ddit_block_forward(x, c, P, n_heads, cos, sin, p_drop, cdt, save, cu_seqlens
             ops.gemm_nt(c_c, compute_weight(link_out.ada_w, cdt), bias=link_out.ada_b.detach(), out=mod_n)
         x2, link_out.h1, link_out.mean1, link_out.rstd1 = ops.gate_residual_ln_modulate_fwd(
             x1, y, mod[:, 5 * D:6 * D], keep2, inv, link_out.norm1_w.detach(), mod_n[:, :D], mod_n[:, D:2 * D])
-        link_out.mod = mod_n
+        link_out.mod, link_out.x2_key = mod_n, BlockLink.key(x2)
         link_out.prev = dict(y=y, gate=mod[:, 5 * D:6 * D], keep2=keep2, inv=inv) if save else None
     else:
         x2 = ops.gate_residual_fwd(x1, y, mod[:, 5 * D:6 * D], keep2, inv)
@@ -302,6 +325,7 @@ def ddit_block_backward(dx2, st, P, n_heads):
     lo = st.get("link_out")
     if lo is not None and lo.dy is not None:
         # the next block's norm1 backward already sent its finished dx (= dx2) through this gated residual's backward
+        lo.check_grad(dx2)
         dy, dmod, grads["mlp.2.bias"] = lo.dy.view(M, D), lo.dmod_prev, lo.db2_fresh
         lo.dy = lo.dmod_prev = lo.db2_fresh = lo.prev = None
     else:
@@ -346,6 +370,7 @@ def ddit_block_backward(dx2, st, P, n_heads):
         li.dy = ops.ln_modulate_bwd_gate(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"],
                                          st["rstd1"], dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D], pv["y"], pv["gate"],
                                          li.dmod_prev[:, 5 * D:6 * D], pv["keep2"], pv["inv"], dbias=db2p)
+        li.dx_key = BlockLink.key(dx)
     else:
         ops.ln_modulate_bwd(dh1.view(B, L, D), x, P["norm1.weight"].detach(), mod[:, D:2 * D], st["mean1"], st["rstd1"],
                             dx, True, dw1, dmod[:, :D], dmod[:, D:2 * D])
@@ -367,7 +392,7 @@ def final_layer_forward(x, c, P, cdt, save, link_in=None):
     link_in: BlockLink with the last block (the LayerNorm-modulate then came out of that block's last pass)."""
     B, L, D = x.shape
     M = B * L
-    chained = link_in is not None and link_in.h1 is not None
+    chained = link_in is not None and link_in.taken_by(x)
     if chained:
         mod, h, mean, rstd = link_in.mod, link_in.h1, link_in.mean1, link_in.rstd1
         link_in.mod = link_in.h1 = link_in.mean1 = link_in.rstd1 = None
@@ -402,6 +427,7 @@ def final_layer_backward(dlogits, st, P):
         li.dy = ops.ln_modulate_bwd_gate(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"],
                                          st["rstd"], dx, False, dw, dmod[:, :D], dmod[:, D:2 * D], pv["y"], pv["gate"],
                                          li.dmod_prev[:, 5 * D:6 * D], pv["keep2"], pv["inv"], dbias=db2p)
+        li.dx_key = BlockLink.key(dx)
     else:
         ops.ln_modulate_bwd(dh.view(B, L, D), x, P["norm_final.weight"].detach(), mod[:, D:2 * D], st["mean"], st["rstd"],
                             dx, False, dw, dmod[:, :D], dmod[:, D:2 * D])

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/sedd_hip.h). Each takes/returns torch CUDA tensors, launches on
 torch's current stream and allocates outputs with torch's caching allocator. No arithmetic happens in Python."""
 import os
+import threading
 
 import torch
 
@@ -85,14 +86,15 @@ _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 def _stream():
     """raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object
     through several Python layers — ~8 us a call, a fifth of the host time of a launch-bound step.)"""
-    if _STREAM_OVERRIDE is not None:
-        return _STREAM_OVERRIDE
+    ov = getattr(_TLS, "stream", None)
+    if ov is not None:
+        return ov
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
-_STREAM_OVERRIDE = None  # raw handle every launch of this module goes to while a SideStream fork is open (see there)
+_TLS = threading.local()  # .stream: raw handle every launch of THIS THREAD goes to while a SideStream fork is open
 
 
 class _RawFork:
@@ -105,12 +107,10 @@ class _RawFork:
         self.raw = raw
 
     def __enter__(self):
-        global _STREAM_OVERRIDE
-        _STREAM_OVERRIDE = self.raw
+        _TLS.stream = self.raw
 
     def __exit__(self, *exc):
-        global _STREAM_OVERRIDE
-        _STREAM_OVERRIDE = None
+        _TLS.stream = None
         return False
 
 
@@ -160,17 +160,16 @@ class SideStream:
             self.flush()
 
     def flush(self):
-        global _STREAM_OVERRIDE
         if not self.pending:
             return
         todo, self.pending = self.pending, []
         with self.fork():
             for fn, torch_ops in todo:
                 if torch_ops:
-                    _STREAM_OVERRIDE = None
+                    _TLS.stream = None
                     with torch.cuda.stream(self.stream):
                         fn()
-                    _STREAM_OVERRIDE = self._raw.raw
+                    _TLS.stream = self._raw.raw
                 else:
                     fn()
 

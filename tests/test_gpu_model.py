@@ -205,6 +205,49 @@ def test_block_boundary_fusion_matches_stand_alone_blocks(dtype, sinks):
     assert torch.equal(run(True, train=False)[0], run(False, train=False)[0])
 
 
+def test_block_boundary_fusion_guards():
+    """a forward hook that REPLACES a block's output breaks the chain silently (the next block runs stand-alone, same
+    results as the unchained model); a second consumer of a block's output is refused in backward instead of producing a
+    wrong gradient."""
+    from protein_lig_sedd_amd.model.transformer import _SEDD
+    from protein_lig_sedd_amd.model import layers as Lyr
+    D, H, C, nb, tokens, B, L = 64, 2, 32, 3, 25, 2, 16
+    sd = seeded_state_dict(sedd_shapes(D, H, C, nb, tokens + 1), seed=52, std=0.05)
+    torch.manual_seed(6)
+    xt = torch.randint(0, tokens + 1, (B, L), device=DEV)
+    sigma = torch.rand(B, device=DEV) * 3 + 0.1
+
+    def build():
+        model = _SEDD(sedd_config(D, H, C, nb, tokens), compute_dtype=torch.float32).to(DEV).train()
+        load_sd(model, sd)
+        return model
+
+    def grads(model, extra=None):
+        out = model(xt, sigma)
+        loss = out.float().square().sum() + (0.0 if extra is None else extra())
+        loss.backward()
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    Lyr.BLOCK_CHAIN = False
+    try:
+        m0 = build()
+        m0.blocks[1].register_forward_hook(lambda mod, inp, out: out * 1.0)
+        o0, g0 = grads(m0)
+    finally:
+        Lyr.BLOCK_CHAIN = True
+    m1 = build()
+    m1.blocks[1].register_forward_hook(lambda mod, inp, out: out * 1.0)  # a new tensor: block 2 must not take the hand-over
+    o1, g1 = grads(m1)
+    assert torch.equal(o1, o0)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 2e-5, k
+    m2 = build()
+    seen = []
+    m2.blocks[0].register_forward_hook(lambda mod, inp, out: seen.append(out))
+    with pytest.raises(RuntimeError, match="second consumer"):
+        grads(m2, extra=lambda: seen[0].sum())
+
+
 def test_kat_init_loss():
     """SURVEY section 4 KAT: with the reference's zero-init the logits are -log(e^sigma-1) - log(V-1) and the loss
     per masked token log(V-1)/(e^sigma-1)."""
