@@ -22,6 +22,7 @@ from . import ops
 from .losses import get_loss_fn
 from .model import layers as Lyr
 from .model.ema import ExponentialMovingAverage
+from .model.transformer import set_training
 
 ALIGN = 64
 
@@ -263,7 +264,7 @@ class SEDDTrainer:
 
             def body(batch, t=None, perturbed_batch=None, u=None, esm_cond=None, mol_cond=None):
                 fl.g.zero_()
-                self.model.train()
+                set_training(self.model, True)
                 loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                                     mol_cond=mol_cond)
                 self._backward(loss)
@@ -272,7 +273,7 @@ class SEDDTrainer:
             return self._graphed_step(body, inputs)[0]
         if self._accum_iter == 0:
             fl.g.zero_()
-        self.model.train()
+        set_training(self.model, True)
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                             mol_cond=mol_cond)
         if self.accum == 1:
@@ -738,7 +739,7 @@ class CrossAttTrainer(SEDDTrainer):
             b = {k[2:]: v for k, v in tensors.items() if k.startswith("b_")}
             pert = {k[2:]: v for k, v in tensors.items() if k.startswith("p_")}
             fl.g.zero_()
-            self.model.train()
+            set_training(self.model, True)
             out = self.calc_loss(b, task, t=t, perturbed=pert)
             loss = out[0].mean() if task == "joint" else out.mean()
             self._backward(loss)
