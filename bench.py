@@ -330,6 +330,24 @@ def main():
         dt = float(tt)
     tokens_per_s = world * B * L * args.steps / dt
 
+    # beside the headline (not part of it): the same step without the roofline's timing events, and with the weight
+    # gradients on the side stream (SEDDTrainer(wgrad_stream=True): same bits; off in the timed region because kernels of
+    # two streams running side by side would make the per-launch event times meaningless)
+    variants = None
+    if not multi:
+        def steps_ms(n):
+            sync()
+            ta = time.perf_counter()
+            for i in range(n):
+                trainer.train_step(batches[i % 4])
+            sync()
+            return 1e3 * (time.perf_counter() - ta) / n
+        variants = {"ms_per_step_no_events": steps_ms(args.steps)}
+        trainer._side = ops.SideStream(dev)
+        steps_ms(2)
+        variants["ms_per_step_wgrad_stream"] = steps_ms(args.steps)
+        trainer._side = None
+
     # second half of the metric: sampled sequences/s at BASELINE configs[4] — the cfg-2 model, Analytic predictor, 1024
     # steps, shape (4096, 1024) sharded 512 per GPU (sampling/run_sample_cond.py:40-42) — measured on `--sample-steps`
     # timed sampler steps (+ the denoiser step) of exactly that per-GPU shard and scaled to the 1025 model evaluations of
@@ -404,6 +422,8 @@ def main():
                          "gemm_ms_per_step": ms_g / max(args.steps, 1)},
             "kernels": others,
         }
+        if variants:
+            out["variants"] = variants
         if samp:
             out["sampling"] = samp
         if world == 1 and not args.no_cpu_baseline:
