@@ -343,7 +343,7 @@ def main():
             sync()
             return 1e3 * (time.perf_counter() - ta) / n
         variants = {"ms_per_step_no_events": steps_ms(args.steps)}
-        trainer._side = ops.SideStream(dev)
+        trainer._side, trainer._side_max = ops.SideStream(dev), None
         steps_ms(2)
         variants["ms_per_step_wgrad_stream"] = steps_ms(args.steps)
         trainer._side = None

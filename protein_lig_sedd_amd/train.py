@@ -112,7 +112,7 @@ class SEDDTrainer:
 
     def __init__(self, model, noise, graph, optim, ema_decay=0.9999, sampling_eps=1e-3, world_size=None,
                  process_group=None, overlap=True, lr_schedule=None, ema=None, conditioners=False, accum=1,
-                 hip_graph=False, grad_comm_dtype=None, zero1=None, wgrad_stream=False):
+                 hip_graph=False, grad_comm_dtype=None, zero1=None, wgrad_stream=None):
         g = (lambda k, d=None: optim.get(k, d)) if isinstance(optim, dict) else (lambda k, d=None: getattr(optim, k, d))
         self.lr, self.beta1, self.beta2 = g("lr", 3e-4), g("beta1", 0.9), g("beta2", 0.999)
         self.eps, self.wd = g("eps", 1e-8), g("weight_decay", 0.0)
@@ -195,11 +195,20 @@ class SEDDTrainer:
         self.rank = dist.get_rank(process_group) if (self.dp and dist.is_initialized()) else 0
         per = self.flat.n // (self.world if self.zero1 else 1)
         self.shard = (self.rank * per, (self.rank + 1) * per) if self.zero1 else (0, self.flat.n)
-        # wgrad_stream=True (opt-in): weight- and bias-gradient launches of backward go to a second stream (ops.SideStream)
-        # and run beside the data-gradient chain; for steps whose kernels each fill a fraction of the chip (small batches)
+        # wgrad_stream: weight- and bias-gradient launches of backward go to a second stream (ops.SideStream) and run
+        # beside the data-gradient chain — for steps whose kernels each fill a fraction of the chip.  True / False, or None
+        # (default) = where it was measured to pay on every box: fp32 compute and steps of at most `_side_max` tokens
+        # (8192).  BASELINE cfg 1 (1024 tokens), same-box A/B x3: fp32 7.94 -> 7.19 ms; bf16 5.2 -> 5.55 ms — that step is
+        # bound by the host's enqueue rate, which the forks add to (on a faster host the same A/B read 5.3 -> 4.9 ms), so
+        # bf16 stays opt-in here; at cfg 2's 32768 tokens every GEMM fills the chip and it buys 0.5 %.
         if os.environ.get("SEDD_WGRAD_STREAM") in ("0", "1"):  # (A/B override)
             wgrad_stream = os.environ["SEDD_WGRAD_STREAM"] == "1"
-        self._side = ops.SideStream(self.flat.p.device) if (wgrad_stream and self.flat.p.is_cuda) else None
+        if wgrad_stream is None and getattr(model, "compute_dtype", None) != torch.float32:
+            wgrad_stream = False
+        if self.overlap:  # the per-block buckets are launched from the backward hooks: a block's weight gradients must be
+            wgrad_stream = False  # in the gradient buffer by then, not waiting in the side stream's queue
+        self._side = ops.SideStream(self.flat.p.device) if (wgrad_stream is not False and self.flat.p.is_cuda) else None
+        self._side_max = int(os.environ.get("SEDD_WGRAD_STREAM_MAX_TOKENS", "8192")) if wgrad_stream is None else None
         self._gb = None  # bf16 staging buffer of the gradient exchange
         self._shards_dirty = False
         if self.zero1:
@@ -267,7 +276,7 @@ class SEDDTrainer:
                 set_training(self.model, True)
                 loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                                     mol_cond=mol_cond)
-                self._backward(loss)
+                self._backward(loss, batch.numel())
                 return (loss,)
 
             return self._graphed_step(body, inputs)[0]
@@ -277,14 +286,14 @@ class SEDDTrainer:
         loss = self.loss_fn(self.model, batch, t=t, perturbed_batch=perturbed_batch, u=u, esm_cond=esm_cond,
                             mol_cond=mol_cond)
         if self.accum == 1:
-            self._backward(loss)
+            self._backward(loss, batch.numel())
             self.apply_gradients()
             return loss.detach()
         if self.overlap:
             raise RuntimeError("gradient accumulation with SEDD_DP_OVERLAP=1: the per-block buckets would all-reduce "
                                "every micro-step; use the default single all-reduce")
         loss = loss / self.accum
-        self._backward(loss)   # every backward kernel ACCUMULATES into the flat gradient buffer
+        self._backward(loss, batch.numel())   # every backward kernel ACCUMULATES into the flat gradient buffer
         self._accum_iter += 1
         self._accum_loss = loss.detach() if self._accum_loss is None else self._accum_loss + loss.detach()
         if self._accum_iter < self.accum:
@@ -408,10 +417,11 @@ class SEDDTrainer:
         trainable set and hyper-parameters other than lr / step / EMA decay are not)."""
         self._graphs, self._graph_calls = {}, {}
 
-    def _backward(self, loss):
-        """loss.backward() with the weight-gradient launches on the side stream when one is configured; on return every
-        gradient launch is ordered before whatever the current stream does next."""
-        if self._side is None:
+    def _backward(self, loss, tokens=None):
+        """loss.backward() with the weight-gradient launches on the side stream when one is configured (and, in the
+        by-size mode, the step has at most `_side_max` tokens); on return every gradient launch is ordered before whatever
+        the current stream does next."""
+        if self._side is None or (self._side_max is not None and (tokens is None or tokens > self._side_max)):
             loss.backward()
             return
         ops.SIDE = self._side
