@@ -304,3 +304,37 @@ def test_g21_plinder_dataset_collate_split_and_shards(golden, tmp_path):
             seen += [int(v) - 3 for v in bt["lig_tokens"][:, 0]]
     tr, _, _ = data.split_indices(23)
     assert set(seen) == set(tr) and len(seen) == 2 * ((len(tr) + 1) // 2)
+
+
+def test_param_lookup_and_mode_setting_helpers():
+    """transformer._params reads the modules' own dictionaries (with the attribute route as fall-back); set_training calls
+    model.train() only when some module is not in the requested mode already — same end state as the reference's
+    unconditional model.train() of every step."""
+    import types
+    import torch.nn as nn
+    from protein_lig_sedd_amd.model import layers as Lyr
+    from protein_lig_sedd_amd.model import transformer as T
+    ns = types.SimpleNamespace
+    cfg = ns(tokens=25, graph=ns(type="absorb"),
+             model=ns(hidden_size=64, cond_dim=32, n_heads=2, n_blocks=2, dropout=0.1, scale_by_sigma=True))
+    m = T._SEDD(cfg)
+    P = T._params(m.blocks[1], Lyr.BLOCK_PARAMS)
+    assert P["mlp.0.weight"] is m.blocks[1].mlp[0].weight and P["adaLN_modulation.bias"] is m.blocks[1].adaLN_modulation.bias
+    assert P["norm1.weight"] is m.blocks[1].norm1.weight and set(P) == set(Lyr.BLOCK_PARAMS)
+
+    class Odd(nn.Module):  # a parameter reached through a plain attribute, not a registered sub-module
+        def __init__(self):
+            super().__init__()
+            object.__setattr__(self, "inner", nn.Linear(2, 2))
+    o = Odd()
+    assert T._params(o, ("inner.weight",))["inner.weight"] is o.inner.weight
+    calls = []
+    orig = m.train
+    m.train = lambda mode=True: (calls.append(mode), orig(mode))[1]
+    T.set_training(m, True)
+    assert calls == []                       # already in train mode everywhere: nothing to do
+    m.blocks[1].eval()
+    T.set_training(m, True)
+    assert calls == [True] and all(mod.training for mod in m.modules())
+    T.set_training(m, False)
+    assert calls == [True, False] and not any(mod.training for mod in m.modules())
