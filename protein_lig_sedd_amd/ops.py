@@ -1,5 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (include/sedd_hip.h). Each takes/returns torch CUDA tensors, launches on
 torch's current stream and allocates outputs with torch's caching allocator. No arithmetic happens in Python."""
+import collections
 import os
 import threading
 
@@ -125,9 +126,12 @@ class SideStream:
     sums are consumed by the optimiser only, while the data gradients feed the next layer's backward.  When the kernels of a
     step each fill a fraction of the chip (the dual-track model at batch 4: 64-128 tiles per GEMM on 256 CUs), the two chains
     run side by side instead of one after the other.  `fork(keep...)`: the side stream waits for everything launched so far
-    on the current stream; the tensors it will read are kept alive until `join()` (the caching allocator would otherwise hand
-    their memory to a later allocation of the main stream while the side stream still reads them).  `join()`: the current
-    stream waits for the side stream.  Capture-safe (events inside a capture become graph edges)."""
+    on the current stream; the tensors it will read are kept alive until the side stream is done with them (the caching
+    allocator would otherwise hand their memory to a later allocation of the main stream while the side stream still reads
+    them): each flushed batch is followed by an event on the side stream and released once that event has completed — so
+    what is held is a few batches, not a whole backward pass of activations and gradients — or at `join()` at the latest.
+    `join()`: the current stream waits for the side stream.  Capture-safe (events inside a capture become graph edges; no
+    event is queried while capturing, the tensors then stay until join)."""
 
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
@@ -138,6 +142,8 @@ class SideStream:
         self._raw = _RawFork(self.stream.cuda_stream)
         self.pending = []
         self.batch = int(os.environ.get("SEDD_SIDE_BATCH", "16"))
+        self._inflight = collections.deque()  # (event on the side stream behind a flushed batch, the tensors it reads)
+        self._done_pool = []
 
     def fork(self, *tensors, torch_ops=False):
         """torch_ops=True: the body also runs torch kernels or allocates temporaries (the slow torch.cuda.stream context);
@@ -154,8 +160,7 @@ class SideStream:
         """queue `fn` for the side stream; the queue is flushed — ONE fork for all of it — every `batch` entries and at
         join().  An event record + stream wait per weight gradient (290 a step in the dual-track model) cost more host
         time than the launches themselves; the deferred launches lose nothing, they are off the critical path."""
-        self.pending.append((fn, torch_ops))
-        self.keep.extend(t for t in tensors if t is not None)
+        self.pending.append((fn, torch_ops, tensors))
         if len(self.pending) >= self.batch:
             self.flush()
 
@@ -164,7 +169,7 @@ class SideStream:
             return
         todo, self.pending = self.pending, []
         with self.fork():
-            for fn, torch_ops in todo:
+            for fn, torch_ops, _ in todo:
                 if torch_ops:
                     _TLS.stream = None
                     with torch.cuda.stream(self.stream):
@@ -172,6 +177,15 @@ class SideStream:
                     _TLS.stream = self._raw.raw
                 else:
                     fn()
+        held = [t for _, _, ts in todo for t in ts if t is not None]
+        if torch.cuda.is_current_stream_capturing():
+            self.keep.extend(held)
+            return
+        ev = self._done_pool.pop() if self._done_pool else torch.cuda.Event()
+        ev.record(self.stream)
+        self._inflight.append((ev, held))
+        while len(self._inflight) > 1 and self._inflight[0][0].query():
+            self._done_pool.append(self._inflight.popleft()[0])
 
     def join(self):
         self.flush()
@@ -179,6 +193,8 @@ class SideStream:
             torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
             self.dirty = False
         self.keep = []
+        while self._inflight:
+            self._done_pool.append(self._inflight.popleft()[0])
 
 
 SIDE = None  # set to a SideStream by a trainer for the duration of a backward pass
