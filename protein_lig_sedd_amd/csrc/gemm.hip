@@ -1743,7 +1743,9 @@ static int gemm_tn_impl(const void* A, int64_t lda, const void* B, int64_t ldb, 
     static const int nosplit_kt = getenv("SEDD_TN_NOSPLIT_KT") ? atoi(getenv("SEDD_TN_NOSPLIT_KT")) : 64;
     const bool nosplit = out_dtype == SEDD_F32 && K / BIG_BK <= nosplit_kt && t128 >= 16;
     // (the 256-wide tile sits at 256 VGPRs: with the column sums' accumulator and selector it spills 71 -> 128-wide then)
-    const bool wide = !nosplit && !colsum && N > 128 && (t256 >= 128 || t128 > 256 || N % 256 == 0);
+    static const int force_wide = getenv("SEDD_TN_WIDE") ? atoi(getenv("SEDD_TN_WIDE")) : -1;  // A/B knob
+    const bool wide = force_wide >= 0 ? (force_wide != 0 && N > 128 && !colsum)
+                                      : !nosplit && !colsum && N > 128 && (t256 >= 128 || t128 > 256 || N % 256 == 0);
     const int bn = wide ? 256 : 128;
     const int64_t tn = (N + bn - 1) / bn, tiles = tm * tn;
     SEDD_CHECK_ARG(tiles < (1LL << 30), "gemm_tn: too many tiles");
