@@ -110,7 +110,7 @@ def cross_block_forward(x, c, other, other_mask, P, n_heads, cos, sin, p_drop, c
     """DDiTBlock.forward (transformers_protlig_cross.py:279-320). x fp32 [B, L, D]; other: None or [B, Lo, D] fp32."""
     B, L, D = x.shape
     M, H, d = B * L, n_heads, D // n_heads
-    c_c = c if cdt == torch.float32 else ops.cast(c, cdt)
+    c_c = c if cdt == torch.float32 else Lyr.cast_once(c, cdt)
     mod = Lyr.linear_fwd(c_c, P["adaLN_modulation.weight"], P["adaLN_modulation.bias"])
     h1, mean1, rstd1 = ops.ln_modulate_fwd(x, P["norm1.weight"].detach(), shift=mod[:, :D], scale=mod[:, D:2 * D],
                                            out_dtype=cdt)
@@ -177,14 +177,14 @@ def cross_block_backward(dx2, st, P, n_heads):
         return sink.get(name, P[name])
 
     dmod = torch.empty(B, 6 * D, dtype=torch.float32, device=x.device)
-    dx = dx2.clone()
+    dx = torch.empty_like(dx2)  # = dx2 + the LayerNorm branches' gradients (dx2 is autograd's and stays untouched)
     # ---- MLP branch
-    dy = ops.gate_residual_bwd(dx, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
+    dy = ops.gate_residual_bwd(dx2, st["y"], mod[:, 5 * D:6 * D], dmod[:, 5 * D:6 * D], st["keep2"], st["inv"]).view(M, D)
     dg = part_bwd(st["g"], dy, P["mlp.2.weight"], P["mlp.2.bias"], 0, D, G("mlp.2.weight"), G("mlp.2.bias"))
     du = ops.gelu_bwd(st["u"], dg)
     dh2 = part_bwd(st["h2"].view(M, D), du, P["mlp.0.weight"], P["mlp.0.bias"], 0, 4 * D, G("mlp.0.weight"), G("mlp.0.bias"))
     ops.ln_modulate_bwd(dh2.view(B, L, D), st["xm"], P["norm2.weight"].detach(), mod[:, 4 * D:5 * D], st["mean2"],
-                        st["rstd2"], dx, True, G("norm2.weight"), dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
+                        st["rstd2"], dx, dx2, G("norm2.weight"), dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D])
     # ---- cross-attention branch: xm = x1 + dropout(out_proj(attn(q(LN(x1)), kv(other))))
     d_other = None
     ca = st["ca"]
